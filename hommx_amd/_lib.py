@@ -1,0 +1,101 @@
+"""ctypes binding of libhommx_hip.so (include/hommx_hip.h).
+
+The library is the product path; there is NO CPU fallback.  If the shared object is missing or
+cannot be loaded, every entry point raises -- loudly -- instead of computing something else.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhommx_hip.so")
+
+# every symbol include/hommx_hip.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "hommx_device_count",
+    "hommx_plan_create",
+    "hommx_plan_destroy",
+    "hommx_plan_num_elements",
+    "hommx_plan_coef_components",
+    "hommx_plan_tensor_size",
+    "hommx_plan_kernel_name",
+    "hommx_solve_batch",
+    "hommx_solve_batch_device",
+    "hommx_calibrate_fp64_mfma",
+    "hommx_last_error",
+)
+
+KIND_POISSON_SCALAR = 0
+KIND_POISSON_MATRIX = 1
+KIND_ELASTICITY_ISO = 2
+KIND_ELASTICITY_VOIGT = 3
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32),
+        ("n_micro", C.c_int32),
+        ("kind", C.c_int32),
+        ("device", C.c_int32),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+class HommxLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libhommx_hip.so (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HommxLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C hommx_amd/csrc` (or __graft_entry__.build()). "
+            "hommx_amd has no CPU fallback for the micro-cell solves."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise HommxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
+    lib.hommx_device_count.restype = C.c_int
+    lib.hommx_device_count.argtypes = []
+    lib.hommx_plan_create.restype = C.c_int
+    lib.hommx_plan_create.argtypes = [C.POINTER(vp), C.POINTER(PlanDesc)]
+    lib.hommx_plan_destroy.restype = C.c_int
+    lib.hommx_plan_destroy.argtypes = [vp]
+    lib.hommx_plan_num_elements.restype = i64
+    lib.hommx_plan_num_elements.argtypes = [vp]
+    lib.hommx_plan_coef_components.restype = i32
+    lib.hommx_plan_coef_components.argtypes = [vp]
+    lib.hommx_plan_tensor_size.restype = i32
+    lib.hommx_plan_tensor_size.argtypes = [vp]
+    lib.hommx_plan_kernel_name.restype = C.c_char_p
+    lib.hommx_plan_kernel_name.argtypes = [vp]
+    lib.hommx_solve_batch.restype = C.c_int
+    lib.hommx_solve_batch.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.hommx_solve_batch_device.restype = C.c_int
+    lib.hommx_solve_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.hommx_calibrate_fp64_mfma.restype = C.c_int
+    lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
+    lib.hommx_last_error.restype = C.c_char_p
+    lib.hommx_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().hommx_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HommxLibraryError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,88 @@
+"""Batched micro-cell solves: the Python face of the C ABI.
+
+``MicroCellPlan.solve`` replaces the macro-cell loop of ``BaseHMM._assemble_stiffness``
+(/root/reference/src/hommx/hmm.py:298-332): one call returns the effective tensor of every
+macro cell of the batch.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+KINDS = {
+    "poisson": _lib.KIND_POISSON_SCALAR,
+    "poisson_matrix": _lib.KIND_POISSON_MATRIX,
+    "elasticity": _lib.KIND_ELASTICITY_ISO,
+    "elasticity_voigt": _lib.KIND_ELASTICITY_VOIGT,
+}
+
+
+class MicroCellPlan:
+    """Everything batch-independent for one (dim, n_micro, kind): kernel choice + device scratch.
+
+    Replaces the per-right-hand-side ``dolfinx_mpc.LinearProblem`` construction of hmm.py:420-425.
+    """
+
+    def __init__(self, dim: int, n_micro: int, kind: str = "poisson", device: int = 0, flags: int = 0):
+        if kind not in KINDS:
+            raise ValueError(f"unknown kind {kind!r}; expected one of {sorted(KINDS)}")
+        self._lib = _lib.load()
+        self.dim, self.n_micro, self.kind, self.device = int(dim), int(n_micro), kind, int(device)
+        desc = _lib.PlanDesc(self.dim, self.n_micro, KINDS[kind], self.device, int(flags))
+        h = C.c_void_p()
+        _lib.check(self._lib.hommx_plan_create(C.byref(h), C.byref(desc)), "hommx_plan_create")
+        self._h = h
+        self.n_el = int(self._lib.hommx_plan_num_elements(h))
+        self.n_comp = int(self._lib.hommx_plan_coef_components(h))
+        self.t = int(self._lib.hommx_plan_tensor_size(h))
+        self.kernel = self._lib.hommx_plan_kernel_name(h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hommx_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host arrays -----------------------------------------------------------------------------
+    def solve(self, coef: np.ndarray, M: np.ndarray | None = None, return_info: bool = False):
+        """coef[N_c, n_el(, n_comp)] float64, M[N_c, d, d] or None -> A_eff[N_c, t, t] (and info[N_c])."""
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        nc = coef.shape[0]
+        if coef.size != nc * self.n_el * self.n_comp:
+            raise ValueError(
+                f"coef has shape {coef.shape}; expected ({nc}, {self.n_el}"
+                + (f", {self.n_comp})" if self.n_comp > 1 else ")")
+            )
+        Mp = None
+        if M is not None:
+            M = np.ascontiguousarray(M, dtype=np.float64)
+            if M.shape != (nc, self.dim, self.dim):
+                raise ValueError(f"M has shape {M.shape}; expected ({nc}, {self.dim}, {self.dim})")
+            Mp = M.ctypes.data
+        out = np.empty((nc, self.t, self.t), dtype=np.float64)
+        info = np.zeros(nc, dtype=np.int32)
+        if nc:
+            _lib.check(
+                self._lib.hommx_solve_batch(self._h, nc, coef.ctypes.data, Mp, out.ctypes.data, info.ctypes.data),
+                "hommx_solve_batch",
+            )
+        return (out, info) if return_info else out
+
+    # -- device pointers (torch tensors or raw ints), asynchronous --------------------------------
+    def solve_device(self, n_cells: int, coef_ptr: int, M_ptr: int | None, out_ptr: int, info_ptr: int | None,
+                     stream: int | None = None):
+        _lib.check(
+            self._lib.hommx_solve_batch_device(
+                self._h, int(n_cells), coef_ptr, M_ptr or None, out_ptr, info_ptr or None, stream or None
+            ),
+            "hommx_solve_batch_device",
+        )

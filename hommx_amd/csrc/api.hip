@@ -1,0 +1,179 @@
+// api.hip -- the C ABI of libhommx_hip.so (include/hommx_hip.h): plan objects, buffers, dispatch.
+//
+// Boundary it implements: the macro-cell loop BaseHMM._assemble_stiffness (hmm.py:298-332) calling
+// _compute_local_stiffness (hmm.py:334-369) once per cell.  Here: one call per batch of cells.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/hommx_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail(e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP, "%s failed: %s", #expr, \
+                  hipGetErrorString(e__));                                                     \
+  } while (0)
+
+enum Family { FAM_FUSED2D = 0, FAM_BLOCKED = 1 };
+
+}  // namespace
+
+struct hommx_plan {
+  hommx_plan_desc desc;
+  Family family;
+  int64_t n_el;
+  int32_t n_comp;
+  int32_t t;
+  // staging buffers for the host-pointer entry point (grown on demand)
+  double* d_coef = nullptr;
+  double* d_M = nullptr;
+  double* d_out = nullptr;
+  int32_t* d_info = nullptr;
+  int64_t cap_cells = 0;
+  hommx::BlockedWorkspace* ws = nullptr;
+};
+
+extern "C" {
+
+int hommx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* hommx_last_error(void) { return g_err.c_str(); }
+
+int hommx_plan_create(hommx_plan** out, const hommx_plan_desc* d) {
+  if (!out || !d) return fail(HOMMX_EINVAL, "null argument");
+  *out = nullptr;
+  if (d->dim != 2 && d->dim != 3) return fail(HOMMX_EINVAL, "dim must be 2 or 3 (hmm.py:104-105), got %d", d->dim);
+  if (d->kind < 0 || d->kind > 3) return fail(HOMMX_EINVAL, "unknown kind %d", d->kind);
+  if (d->n_micro < 3) return fail(HOMMX_EINVAL, "n_micro must be >= 3 (got %d): with fewer cells per side periodic neighbours coincide", d->n_micro);
+  int ndev = hommx_device_count();
+  if (ndev <= 0) return fail(HOMMX_ENODEV, "no HIP device visible");
+  if (d->device < 0 || d->device >= ndev) return fail(HOMMX_EINVAL, "device %d out of range [0,%d)", d->device, ndev);
+
+  hommx_plan* p = new (std::nothrow) hommx_plan();
+  if (!p) return fail(HOMMX_ENOMEM, "host allocation failed");
+  p->desc = *d;
+  const int dim = d->dim, n = d->n_micro;
+  p->n_el = (dim == 2) ? 2ll * n * n : 6ll * n * n * n;
+  const int tp = dim;                    // Poisson tensor size
+  const int te = dim * (dim + 1) / 2;    // elasticity (Voigt) tensor size
+  switch (d->kind) {
+    case HOMMX_KIND_POISSON_SCALAR: p->n_comp = 1; p->t = tp; break;
+    case HOMMX_KIND_POISSON_MATRIX: p->n_comp = dim * (dim + 1) / 2; p->t = tp; break;
+    case HOMMX_KIND_ELASTICITY_ISO: p->n_comp = 2; p->t = te; break;
+    default: p->n_comp = te * (te + 1) / 2; p->t = te; break;
+  }
+  p->family = (dim == 2 && d->kind == HOMMX_KIND_POISSON_SCALAR && n <= 32 && !(d->flags & 1)) ? FAM_FUSED2D : FAM_BLOCKED;
+  if (p->family == FAM_BLOCKED) {
+    int rc = hommx::blocked_workspace_create(&p->ws, dim, n, d->kind);
+    if (rc != 0) {
+      delete p;
+      return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+    }
+  }
+  *out = p;
+  return HOMMX_OK;
+}
+
+int hommx_plan_destroy(hommx_plan* p) {
+  if (!p) return HOMMX_OK;
+  hipSetDevice(p->desc.device);
+  if (p->d_coef) hipFree(p->d_coef);
+  if (p->d_M) hipFree(p->d_M);
+  if (p->d_out) hipFree(p->d_out);
+  if (p->d_info) hipFree(p->d_info);
+  if (p->ws) hommx::blocked_workspace_destroy(p->ws);
+  delete p;
+  return HOMMX_OK;
+}
+
+int64_t hommx_plan_num_elements(const hommx_plan* p) { return p ? p->n_el : 0; }
+int32_t hommx_plan_coef_components(const hommx_plan* p) { return p ? p->n_comp : 0; }
+int32_t hommx_plan_tensor_size(const hommx_plan* p) { return p ? p->t : 0; }
+const char* hommx_plan_kernel_name(const hommx_plan* p) {
+  if (!p) return "";
+  return p->family == FAM_FUSED2D ? "fused2d" : "blocked";
+}
+
+int hommx_solve_batch_device(hommx_plan* p, int64_t n_cells, const double* d_coef, const double* d_M,
+                             double* d_A_eff, int32_t* d_info, void* stream) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (!d_coef || !d_A_eff) return fail(HOMMX_EINVAL, "null coef / A_eff");
+  if (n_cells > 0x7fffffffll) return fail(HOMMX_EINVAL, "n_cells too large for one launch");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p->family == FAM_FUSED2D) {
+    HIP_TRY(hommx::launch_poisson2d_fused(d_coef, d_M, d_A_eff, d_info, p->desc.n_micro, n_cells, st));
+    return HOMMX_OK;
+  }
+  int rc = hommx::blocked_solve(p->ws, n_cells, d_coef, d_M, d_A_eff, d_info, st);
+  if (rc != 0) return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+  return HOMMX_OK;
+}
+
+int hommx_solve_batch(hommx_plan* p, int64_t n_cells, const double* coef, const double* M, double* A_eff,
+                      int32_t* info) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (!coef || !A_eff) return fail(HOMMX_EINVAL, "null coef / A_eff");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  const int d = p->desc.dim, t = p->t;
+  if (n_cells > p->cap_cells) {
+    if (p->d_coef) hipFree(p->d_coef);
+    if (p->d_M) hipFree(p->d_M);
+    if (p->d_out) hipFree(p->d_out);
+    if (p->d_info) hipFree(p->d_info);
+    p->d_coef = p->d_M = p->d_out = nullptr;
+    p->d_info = nullptr;
+    p->cap_cells = 0;
+    HIP_TRY(hipMalloc(&p->d_coef, sizeof(double) * n_cells * p->n_el * p->n_comp));
+    HIP_TRY(hipMalloc(&p->d_M, sizeof(double) * n_cells * d * d));
+    HIP_TRY(hipMalloc(&p->d_out, sizeof(double) * n_cells * t * t));
+    HIP_TRY(hipMalloc(&p->d_info, sizeof(int32_t) * n_cells));
+    p->cap_cells = n_cells;
+  }
+  HIP_TRY(hipMemcpy(p->d_coef, coef, sizeof(double) * n_cells * p->n_el * p->n_comp, hipMemcpyHostToDevice));
+  if (M) HIP_TRY(hipMemcpy(p->d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
+  int rc = hommx_solve_batch_device(p, n_cells, p->d_coef, M ? p->d_M : nullptr, p->d_out, p->d_info, nullptr);
+  if (rc != HOMMX_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(A_eff, p->d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
+  if (info) HIP_TRY(hipMemcpy(info, p->d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
+  return HOMMX_OK;
+}
+
+int hommx_calibrate_fp64_mfma(int device, double* flops_per_s) {
+  if (!flops_per_s) return fail(HOMMX_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hommx::run_fp64_mfma_calibration(flops_per_s));
+  return HOMMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+/*
+ * hommx_hip.h -- C ABI of libhommx_hip.so: the MI355X (gfx950) batched micro-cell solver that
+ * replaces the per-macro-cell loop of flxrcz/hommx.
+ *
+ * The reference has no FFI layer; its seam is Python:
+ *
+ *   BaseHMM._assemble_stiffness()            src/hommx/hmm.py:298-332   loop over owned macro cells
+ *     -> _compute_local_stiffness(cell)      src/hommx/hmm.py:334-369   nb corrector solves + nb^2 energies
+ *          -> PeriodicLinearProblem.solve()  src/hommx/cell_problem.py:363-388
+ *
+ * This library replaces the LOOP: one call computes the effective tensor A_H / C_H of every macro
+ * cell of a batch; the Python host (hommx_amd/hmm.py) turns it into S_loc = vol(T) G A_H G^T and
+ * scatters on the CPU exactly where the reference calls MatSetValues (hmm.py:325-330).
+ *
+ * All arrays are C-contiguous, float64 / int32.  Plain pointers and sizes only; no torch types.
+ * Every function returns 0 on success or a negative HOMMX_E* code; hommx_last_error() returns a
+ * thread-local message.  Numerical failures are reported per cell in info[] (the reference logs
+ * and continues: hmm.py:320-323, 427-430), never by the return code.
+ */
+#ifndef HOMMX_HIP_H
+#define HOMMX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOMMX_OK 0
+#define HOMMX_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define HOMMX_EHIP (-2)     /* HIP runtime error (message in hommx_last_error) */
+#define HOMMX_ENODEV (-3)   /* no usable GPU */
+#define HOMMX_ENOMEM (-4)   /* device allocation failed */
+
+/* problem kinds: which bilinear form of hmm.py the plan assembles */
+#define HOMMX_KIND_POISSON_SCALAR 0     /* hmm.py:644-667 (and :759-789 when M != NULL); coef[cell][el]            */
+#define HOMMX_KIND_POISSON_MATRIX 1     /* same forms, matrix-valued A; coef[cell][el][d(d+1)/2] (00,11,[22,]01[,02,12]) */
+#define HOMMX_KIND_ELASTICITY_ISO 2     /* hmm.py:887-922 (and :1024-1067 when M != NULL); coef[cell][el][2]=(lambda,mu) */
+#define HOMMX_KIND_ELASTICITY_VOIGT 3   /* same forms, full Hooke tensor; coef[cell][el][t(t+1)/2], upper triangle of
+                                           the t x t matrix  E^m : A : E^n  (tensorial unit strains), row-major */
+
+typedef struct hommx_plan hommx_plan;
+
+typedef struct hommx_plan_desc {
+  int32_t dim;      /* 2 or 3 (hmm.py:104-105)                                                    */
+  int32_t n_micro;  /* micro cells per side of the unit-cell mesh create_unit_square/cube(n,n[,n]) */
+  int32_t kind;     /* HOMMX_KIND_*                                                                */
+  int32_t device;   /* HIP device ordinal                                                          */
+  int32_t flags;    /* reserved, 0                                                                 */
+  int32_t reserved[3];
+} hommx_plan_desc;
+
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int hommx_device_count(void);
+
+/* Create / destroy a plan = everything that does not depend on the batch: kernel selection,
+ * stencil tables, device scratch.  Replaces the per-solve object construction of hmm.py:420-425
+ * (dolfinx_mpc.LinearProblem.__init__: sparsity pattern + Mat + Vec + KSP for EVERY rhs of EVERY cell). */
+int hommx_plan_create(hommx_plan** out, const hommx_plan_desc* desc);
+int hommx_plan_destroy(hommx_plan* plan);
+
+/* Shape queries: elements per micro mesh (2 n^2 / 6 n^3), coefficient doubles per element,
+ * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), and the name of the
+ * kernel family the plan dispatches to ("fused2d" / "blocked"). */
+int64_t hommx_plan_num_elements(const hommx_plan* plan);
+int32_t hommx_plan_coef_components(const hommx_plan* plan);
+int32_t hommx_plan_tensor_size(const hommx_plan* plan);
+const char* hommx_plan_kernel_name(const hommx_plan* plan);
+
+/*
+ * Solve a batch of macro cells (host pointers; the call copies in, runs, copies out, synchronises).
+ *
+ *   coef   [n_cells][n_el][n_comp]  element means of A(c_T, y) (hmm.py:190-198, 349-352) in the element
+ *                                   order  el = n_sub*(i + n*j [+ n*n*k]) + s  of the DOLFINx-style mesh
+ *   M      [n_cells][d][d] or NULL  Dtheta_transpose(c_T), M[i][j] = d theta_j / d x_i (hmm.py:741, 756-757)
+ *   A_eff  [n_cells][t][t]          out: effective tensor = vol(Y)^-1 * the functional of hmm.py:652-667 /
+ *                                   774-789 / 905-922 / 1050-1067 on the canonical unit gradients / strains
+ *   info   [n_cells] or NULL        out: 0 ok; k>0 non-positive or NaN pivot first seen in block step k-1
+ */
+int hommx_solve_batch(hommx_plan* plan, int64_t n_cells, const double* coef, const double* M,
+                      double* A_eff, int32_t* info);
+
+/* Same with DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
+ * Nothing is retained after return; the caller synchronises the stream before reading A_eff. */
+int hommx_solve_batch_device(hommx_plan* plan, int64_t n_cells, const double* d_coef, const double* d_M,
+                             double* d_A_eff, int32_t* d_info, void* stream);
+
+/* Calibration micro-benchmark: sustained fp64 MFMA rate (v_mfma_f64_16x16x4_f64, all CUs), in FLOP/s.
+ * Used by bench.py to state the fp64 matrix peak next to the datasheet figure. */
+int hommx_calibrate_fp64_mfma(int device, double* flops_per_s);
+
+const char* hommx_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOMMX_HIP_H */
