@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the HOMMX micro-cell hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: for every macro cell of the
+configuration C2 of BASELINE.json (2D PoissonHMM, 64x64 macro mesh = 8192 triangles, 32x32 periodic
+micro cells, inclusion coefficient) assemble the periodic micro problem, solve it, reduce to the
+effective tensor A_H.  Inputs are resident in HBM before the timed region.  With N > 1 GPUs every rank
+owns its own 8192-cell macro partition (weak scaling, the reference's MPI partition of hmm.py:307-310)
+and the step ends with ONE RCCL all-gather of the effective-tensor field.
+
+Prints ONE JSON line on rank 0 (contract: metric/value/unit/..., plus `roofline` and `cpu_baseline`).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+FP64_PEAK_DATASHEET = 78.6e12  # FLOP/s, AMD MI355X datasheet: FP64 vector == FP64 matrix (absent from the local guide)
+
+
+def flop_model(n: int) -> float:
+    """Dense block-cyclic model of what the fused kernel executes per micro-cell solve:
+    per eliminated node row: symmetric sweep 2 b^3 + V' = W N 2 b^3 + S_last += V' W^T 2 b^3, b = n;
+    n-1 such rows + the final sweep of the last block."""
+    b = float(n)
+    return (6.0 * (n - 1) + 2.0) * b**3
+
+
+def algorithmic_bytes(n: int, stratified: bool) -> float:
+    """coefficient stream + (M) + A_H."""
+    return 8.0 * (2 * n * n + (4 if stratified else 0) + 4)
+
+
+def cpu_baseline(coef: np.ndarray, n: int, vols_X: np.ndarray, budget_s: float = 15.0):
+    """Reference-shaped CPU path (oracle, 1 core) on a bounded sample of the same workload."""
+    from oracle import hommx_oracle as O
+
+    t0 = time.perf_counter()
+    done = 0
+    AH = []
+    while done < coef.shape[0]:
+        S = O.local_stiffness_reference_shaped("poisson", 2, n, vols_X[done], coef[done], 2.0**-8)
+        cp = O.build_cell_problem("poisson", 2, n, coef[done])
+        AH.append(O.effective_tensor(cp))
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done, np.stack(AH)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--macro", type=int, default=64, help="macro cells per side (C2: 64)")
+    ap.add_argument("--micro", type=int, default=32, help="micro cells per side (C2: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hommx_amd import MicroCellPlan, workloads
+    from hommx_amd.dist import all_gather_field
+
+    n = args.micro
+    # rank r owns the macro partition [r, r+1] x [0, 1] of a (world x 1) strip of unit squares
+    msh, coef_h, _ = workloads.c2_inclusion(args.macro, n, x_shift=float(rank))
+    nc = coef_h.shape[0]
+    plan = MicroCellPlan(2, n, "poisson", device=local_rank)
+    coef = torch.from_numpy(coef_h).to(dev)
+    out = torch.empty(nc, 2, 2, dtype=torch.float64, device=dev)
+    info = torch.zeros(nc, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        plan.solve_device(nc, coef.data_ptr(), None, out.data_ptr(), info.data_ptr(), stream.cuda_stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            return all_gather_field(out, world * nc)
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        field = step(evs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # HIP events on the launch stream
+    n_bad = int((info != 0).sum().item())
+
+    if rank == 0:
+        value = world * nc * args.steps / dt
+        flops = flop_model(n) * nc
+        achieved = flops / (kern_ms * 1e-3)
+        rec = {
+            "metric": "micro-cell solves/sec",
+            "value": value,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: 2D PoissonHMM, {args.macro}x{args.macro} macro P1 mesh ({nc} cells per GPU), "
+                f"{n}x{n} periodic micro cells, inclusion coefficient",
+                "cells_per_gpu": nc,
+                "n_micro": n,
+                "kernel": plan.kernel,
+                "parallelism": f"macro-cell shards x{world}" + (", RCCL all-gather of A_H" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": achieved / 1e12,
+                "peak": FP64_PEAK_DATASHEET / 1e12,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_DATASHEET,
+                "traffic": None,
+                "kernel": "k_poisson2d_fused<32>" if n > 16 else "k_poisson2d_fused<16>",
+                "kernel_ms": kern_ms,
+                "flops_per_solve": flop_model(n),
+                "hbm_bytes_per_solve_algorithmic": algorithmic_bytes(n, False),
+                "hbm_frac_algorithmic": algorithmic_bytes(n, False) * nc / (kern_ms * 1e-3) / 8.0e12,
+            },
+            "info_nonzero": n_bad,
+        }
+        # fp64 MFMA calibration (the local guide lists no f64 matrix peak)
+        try:
+            import ctypes
+
+            from hommx_amd import _lib
+
+            f = ctypes.c_double()
+            _lib.check(_lib.load().hommx_calibrate_fp64_mfma(local_rank, ctypes.byref(f)), "calibrate")
+            rec["roofline"]["peak_measured_mfma_f64"] = f.value / 1e12
+        except Exception as e:  # pragma: no cover
+            rec["roofline"]["peak_measured_mfma_f64"] = None
+            print(f"[bench] calibration failed: {e}", file=sys.stderr)
+        if not args.no_cpu_baseline and world == 1:
+            X = msh.cell_vertices()
+            rate, ndone, AH_cpu = cpu_baseline(coef_h, n, X)
+            AH_gpu = field[:ndone].cpu().numpy()
+            err = float(np.max(np.linalg.norm(AH_gpu - AH_cpu, axis=(1, 2)) / np.linalg.norm(AH_cpu, axis=(1, 2))))
+            rec["cpu_baseline"] = {
+                "value": rate,
+                "unit": "solves/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": f"first {ndone} macro cells of the same batch; oracle restatement of hmm.py:334-369 "
+                "(3 corrector solves + 9 energies per cell, SciPy splu), host cores available: "
+                f"{os.cpu_count()}",
+            }
+            rec["effective_tensor_max_rel_err_vs_oracle"] = err
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
