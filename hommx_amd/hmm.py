@@ -1,0 +1,437 @@
+"""HMM solver classes with the constructor / ``solve()`` surface of flxrcz/hommx (``src/hommx/hmm.py``), driving the
+batched HIP micro-cell solver instead of the per-cell DOLFINx/PETSc loop.
+
+What is kept from the reference:
+  * class names, constructor argument order, ``solve()``, ``set_boundary_conditions``, ``set_right_hand_side``,
+    ``function_space`` (hmm.py:63-73, 173-176, 276-296, 434; class signatures :561-571, :717-728, :843-853, :976-987);
+  * the log-don't-raise error convention (hmm.py:320-323, 427-430) and the ``_needs_reassembly`` cache (hmm.py:150, 287, 300-301, 332);
+  * default homogeneous Dirichlet conditions for ``PoissonHMM`` (hmm.py:598-636), none for elasticity (hmm.py:806-807);
+  * the macro algorithm of ``solve()`` (hmm.py:434-491): assemble, lift Dirichlet values bc by bc, zero rows+columns, solve.
+What differs (DOLFINx/UFL/PETSc are not dependencies):
+  * meshes are ``hommx_amd.mesh.Mesh``; ``A(x, y)``, ``f(x)``, ``Dtheta_transpose(x)`` are NumPy-vectorised callables
+    (x: the cell midpoint, 3 components as the ``fem.Constant`` of hmm.py:190-192; y: array [dim, npts]);
+  * the micro problems of ALL macro cells are solved in one batched GPU call (``_assemble_stiffness``);
+  * the macro system is solved with a sparse direct solver (SciPy); ``petsc_options_*`` are accepted for signature
+    compatibility and are advisory (a direct solve has no tolerance; the reference's own tightest test also uses LU,
+    test_integration_poisson.py:207-212).
+The micro solves have NO CPU path in this package: without the HIP library / a GPU, ``solve()`` raises.
+"""
+
+from __future__ import annotations
+
+import logging
+from abc import ABC, abstractmethod
+from collections.abc import Callable
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import fem
+from .batch import MicroCellPlan
+from .mesh import Mesh, micro_cells_per_side
+
+_VOIGT = {2: [(0, 0), (1, 1), (0, 1)], 3: [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]}
+
+
+def _unroll_dofs(dofs: np.ndarray, bs: int) -> np.ndarray:
+    """hmm.py:31-40."""
+    dofs = np.asarray(dofs)
+    if bs == 1:
+        return dofs
+    return (dofs[..., None] * bs + np.arange(bs)).reshape(dofs.shape[:-1] + (-1,))
+
+
+def micro_quadrature(dim: int, degree: int):
+    """Barycentric points / weights of the rule UFL+Basix would pick for the coefficient:
+    degree <= 1 centroid; 2: 3 / 4 points; 3: 6-point Strang-Fix (triangle), 5-point Keast (tetrahedron)."""
+    import itertools
+
+    if degree <= 1:
+        return np.full((1, dim + 1), 1.0 / (dim + 1)), np.ones(1)
+    if dim == 2 and degree == 2:
+        p = np.full((3, 3), 1.0 / 6.0)
+        np.fill_diagonal(p, 2.0 / 3.0)
+        return p, np.full(3, 1.0 / 3.0)
+    if dim == 2 and degree == 3:
+        a, b, c = 0.659027622374092, 0.231933368553031, 0.109039009072877
+        return np.array(list(itertools.permutations((a, b, c)))), np.full(6, 1.0 / 6.0)
+    if dim == 3 and degree == 2:
+        a, b = 0.5854101966249685, 0.1381966011250105
+        p = np.full((4, 4), b)
+        np.fill_diagonal(p, a)
+        return p, np.full(4, 0.25)
+    if dim == 3 and degree == 3:
+        p = np.full((5, 4), 1.0 / 6.0)
+        p[0] = 0.25
+        for i in range(4):
+            p[i + 1, i] = 0.5
+        return p, np.array([-0.8, 0.45, 0.45, 0.45, 0.45])
+    return fem.simplex_quadrature(dim, degree)
+
+
+def hooke_to_voigt(C: np.ndarray, dim: int) -> np.ndarray:
+    """[..., d,d,d,d] -> [..., t, t] with Cv[m][n] = E^m : C : E^n for the tensorial unit strains E^m."""
+    pairs = _VOIGT[dim]
+    t = len(pairs)
+    out = np.empty(C.shape[:-4] + (t, t))
+    for m, (i, j) in enumerate(pairs):
+        for n, (k, l) in enumerate(pairs):
+            out[..., m, n] = 0.25 * (C[..., i, j, k, l] + C[..., j, i, k, l] + C[..., i, j, l, k] + C[..., j, i, l, k])
+    return out
+
+
+class Lame:
+    """Isotropic Hooke tensor given by its Lame parameters: ``A = lambda d_ij d_kl + mu (d_ik d_jl + d_il d_jk)``
+    (test_integration_linear_elasticity.py:84-93; rotated_fibers.py:66-76).  Returning ``Lame(lam, mu)`` from the
+    coefficient callable selects the 2-component isotropic kernel instead of the 21-component Voigt one."""
+
+    def __init__(self, lam, mu):
+        self.lam, self.mu = lam, mu
+
+
+def isotropic_hooke(lam, mu, dim: int) -> np.ndarray:
+    lam, mu = np.asarray(lam, float), np.asarray(mu, float)
+    I = np.eye(dim)
+    t1 = np.einsum("ij,kl->ijkl", I, I)
+    t2 = np.einsum("ik,jl->ijkl", I, I) + np.einsum("il,jk->ijkl", I, I)
+    return lam[..., None, None, None, None] * t1 + mu[..., None, None, None, None] * t2
+
+
+class BaseHMM(ABC):
+    """hmm.py:53-511."""
+
+    _kind = "poisson"
+
+    def __init__(
+        self,
+        msh: Mesh,
+        A: Callable,
+        f: Callable,
+        msh_micro: Mesh,
+        eps: float,
+        petsc_options_global_solve: dict | None = None,
+        petsc_options_cell_problem: dict | None = None,
+        petsc_options_prefix: str = "hommx_HMM",
+        *,
+        quadrature_degree: int = 0,
+        rhs_quadrature_degree: int = 6,
+        device: int = 0,
+    ):
+        self._logger = logging.getLogger(__name__)
+        self._msh = msh
+        self._comm = msh.comm
+        self._coeff = A
+        self._f = f
+        self._eps = eps
+        self._cell_mesh = msh_micro
+        self._tdim = msh.topology.dim
+        if self._tdim not in (2, 3):
+            raise ValueError("Topology should be 3D or 2D")  # hmm.py:104-105
+        if self._tdim != msh.geometry.dim:
+            raise ValueError(
+                "Topological dimension is different from geometrical dimension. Currently surfaces in 3D are not supported."
+            )
+        if msh_micro.topology.dim != msh_micro.geometry.dim:
+            raise ValueError("Topological dimension is different from geometrical dimension for micro mesh.")
+        if self._tdim != msh_micro.topology.dim:
+            raise ValueError("Micro and macro mesh should have the same dimensionality.")  # hmm.py:114-115
+        self._n_micro = micro_cells_per_side(msh_micro)
+        self._cell_mesh_area = float(msh_micro.cell_volumes().sum())  # hmm.py:101
+        self._quadrature_degree = quadrature_degree
+        self._rhs_degree = rhs_quadrature_degree
+        self._device = device
+
+        self._V_macro = self._setup_macro_function_space()
+        self._macro_coordinates = self._V_macro.tabulate_dof_coordinates()
+        self._bs = self._V_macro.bs
+        self._num_basis_functions_per_cell = (self._tdim + 1) * self._bs  # hmm.py:138-140
+        self._num_global_dofs = self._V_macro.num_dofs
+        self._u = fem.Function(self._V_macro)
+        self._A = None
+        self._needs_reassembly = True
+        if petsc_options_cell_problem is None:
+            petsc_options_cell_problem = {"ksp_atol": 1e-10}  # hmm.py:153-155 (advisory here)
+        self._petsc_options_cell_problem = petsc_options_cell_problem
+        self._petsc_options_global_solve = petsc_options_global_solve
+        self._petsc_options_prefix = petsc_options_prefix
+        self._bcs: list[fem.DirichletBC] = []
+        self._Dtheta_t = None
+        self._plan: MicroCellPlan | None = None
+        self.effective_tensors: np.ndarray | None = None  # A_H / C_H of every macro cell after assembly
+        self.cell_info: np.ndarray | None = None
+
+    # -- API ---------------------------------------------------------------------------------------
+    @property
+    def function_space(self) -> fem.FunctionSpace:
+        """Function space of the macro mesh (hmm.py:173-176)."""
+        return self._V_macro
+
+    def set_boundary_conditions(self, bcs):
+        """hmm.py:276-287."""
+        self._bcs = bcs if isinstance(bcs, list) else [bcs]
+        self._needs_reassembly = True
+
+    def set_right_hand_side(self, f: Callable):
+        """hmm.py:289-296."""
+        self._f = f
+
+    @abstractmethod
+    def _setup_macro_function_space(self) -> fem.FunctionSpace: ...
+
+    # -- coefficient sampling (hmm.py:190-198, 349-352) ---------------------------------------------
+    def _sample_one(self, c_T: np.ndarray, yq: np.ndarray):
+        """A(c_T, y) at the quadrature points yq[dim, npts] -> array [npts, ...] (or Lame)."""
+        v = self._coeff(c_T, yq)
+        if isinstance(v, Lame):
+            lam = np.broadcast_to(np.asarray(v.lam, float), (yq.shape[1],))
+            mu = np.broadcast_to(np.asarray(v.mu, float), (yq.shape[1],))
+            return np.stack([lam, mu], axis=-1)
+        v = np.asarray(v, dtype=float)
+        if v.ndim == 0 or v.shape[0] != yq.shape[1]:
+            v = np.broadcast_to(v, (yq.shape[1],) + v.shape).copy()
+        return v
+
+    def _element_means(self, cells: np.ndarray) -> tuple[np.ndarray, str]:
+        d, n = self._tdim, self._n_micro
+        bary, w = micro_quadrature(d, self._quadrature_degree)
+        Xe = self._cell_mesh.cell_vertices()  # [n_el, d+1, d]
+        yq = np.einsum("qa,eak->eqk", bary, Xe)
+        n_el, nq = yq.shape[:2]
+        yflat = yq.reshape(-1, d).T
+        c = self._msh.cell_midpoints()[cells]
+        first = self._sample_one(c[0], yflat)
+        out = np.empty((len(cells),) + (n_el,) + first.shape[1:])
+        for k in range(len(cells)):
+            v = first if k == 0 else self._sample_one(c[k], yflat)
+            out[k] = np.tensordot(w, v.reshape((n_el, nq) + v.shape[1:]), axes=([0], [1]))
+        return self._pack_coefficient(out)
+
+    def _pack_coefficient(self, means: np.ndarray) -> tuple[np.ndarray, str]:
+        """Element means -> the layout of include/hommx_hip.h for the plan kind."""
+        d = self._tdim
+        if self._kind == "poisson":
+            if means.ndim == 2:
+                return means, "poisson"
+            if means.shape[-2:] == (d, d):
+                pairs = _VOIGT[d]
+                return np.stack([0.5 * (means[..., i, j] + means[..., j, i]) for i, j in pairs], axis=-1), "poisson_matrix"
+            raise ValueError(f"PoissonHMM coefficient must be scalar or {d}x{d}; got trailing shape {means.shape[2:]}")
+        if means.ndim == 3 and means.shape[-1] == 2:
+            return means, "elasticity"
+        if means.shape[-4:] == (d, d, d, d):
+            cv = hooke_to_voigt(means, d)
+            t = cv.shape[-1]
+            iu = np.triu_indices(t)
+            return cv[..., iu[0], iu[1]], "elasticity_voigt"
+        raise ValueError("elasticity coefficient must be Lame(lam, mu) or a [d,d,d,d] tensor")
+
+    def _stratification(self, cells: np.ndarray) -> np.ndarray | None:
+        if self._Dtheta_t is None:
+            return None
+        c = self._msh.cell_midpoints()[cells]
+        d = self._tdim
+        M = np.empty((len(cells), d, d))
+        for k in range(len(cells)):
+            m = np.asarray(self._Dtheta_t(c[k]), dtype=float)
+            if m.shape != (d, d):
+                raise ValueError(f"Dtheta_transpose must return a {d}x{d} matrix (hmm.py:741, :762); got {m.shape}")
+            M[k] = m
+        return M
+
+    # -- the hot path (replaces the loop hmm.py:298-332) ---------------------------------------------
+    def _effective_tensors(self, cells: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        coef, kind = self._element_means(cells)
+        M = self._stratification(cells)
+        if self._plan is None or self._plan.kind != kind:
+            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
+        import sys
+
+        dist = sys.modules.get("torch.distributed")  # only shard when the caller already runs under torch.distributed
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .dist import solve_sharded
+
+            AH = solve_sharded(self._plan, coef, M)
+            return AH, np.zeros(len(cells), dtype=np.int32)
+        return self._plan.solve(coef, M, return_info=True)
+
+    def _local_stiffness_from_tensors(self, cells: np.ndarray, AH: np.ndarray) -> np.ndarray:
+        """S_loc = vol(T)/vol(Y) * (macro gradients) A_H (macro gradients)^T  == hmm.py:361-369."""
+        d, bs = self._tdim, self._bs
+        X = self._msh.cell_vertices()[cells]  # [nc, d+1, d]
+        ones = np.ones(X.shape[:2] + (1,))
+        Minv = np.linalg.inv(np.concatenate([ones, X], axis=2))
+        G = np.transpose(Minv[:, 1:, :], (0, 2, 1))  # [nc, a, d]  grad phi_a
+        vol = self._msh.cell_volumes()[cells] / self._cell_mesh_area
+        if bs == 1:
+            return vol[:, None, None] * np.einsum("cai,cij,cbj->cab", G, AH, G)
+        pairs = _VOIGT[d]
+        I = np.eye(d)
+        eps = 0.5 * (np.einsum("pi,caj->capij", I, G) + np.einsum("pj,cai->capij", I, G))
+        eps = eps.reshape(len(cells), (d + 1) * bs, d, d)
+        Wv = np.stack([eps[:, :, k, l] * (1.0 if k == l else 2.0) for (k, l) in pairs], axis=-1)
+        return vol[:, None, None] * np.einsum("cam,cmn,cbn->cab", Wv, AH, Wv)
+
+    def _compute_local_stiffness(self, cell_index: int) -> np.ndarray:
+        """Single-cell form of the reference seam (hmm.py:334-369): a batch of one."""
+        cells = np.array([cell_index])
+        AH, info = self._effective_tensors(cells)
+        return self._local_stiffness_from_tensors(cells, AH)[0]
+
+    def _assemble_stiffness(self):
+        """hmm.py:298-332 with the cell loop replaced by one batched call."""
+        if not self._needs_reassembly:
+            return
+        cells = np.arange(self._msh.num_cells)
+        AH, info = self._effective_tensors(cells)
+        S = self._local_stiffness_from_tensors(cells, AH)
+        bad = np.nonzero((info != 0) | np.isnan(S).any(axis=(1, 2)))[0]
+        for c in bad:  # hmm.py:320-323: log, do not raise
+            self._logger.error(f"Something went wrong when calculating local matrix on cell {c}")
+        dofs = _unroll_dofs(self._msh.cells.astype(np.int64), self._bs)  # [nc, nb]
+        nb = dofs.shape[1]
+        rows = np.repeat(dofs, nb, axis=1).ravel()
+        cols = np.tile(dofs, (1, nb)).ravel()
+        N = self._num_global_dofs
+        self._A = sp.coo_matrix((S.ravel(), (rows, cols)), shape=(N, N)).tocsr()  # MatSetValues(ADD), hmm.py:325-330
+        self.effective_tensors, self.cell_info = AH, info
+        self._needs_reassembly = False
+
+    def solve(self) -> fem.Function:
+        """Assemble the LHS, RHS and solve the problem (hmm.py:434-491)."""
+        self._assemble_stiffness()
+        A = self._A.copy()
+        b = fem.assemble_load_vector(self._V_macro, self._f, self._rhs_degree)
+        for bc in self._bcs:  # hmm.py:453-480, bc by bc
+            idx, val = bc.unrolled()
+            u_bc = np.zeros(self._num_global_dofs)
+            u_bc[idx] = val
+            b_lift = A @ u_bc
+            b[idx] = val
+            b -= b_lift
+            A = _zero_rows_columns(A, idx)
+            b[idx] = val
+        # the reference caches the BC-modified matrix; keep the clean one and re-apply -- same result
+        if np.isnan(b).any() or np.isnan(A.data).any():
+            self._logger.error("Something went wrong in the global problem solve. NaN in the assembled system")
+        x = spla.spsolve(A.tocsc(), b)
+        self._u.x.array[:] = x
+        return self._u
+
+    def plot_solution(self, u=None):  # hmm.py:493-511 (visualisation: out of scope)
+        raise NotImplementedError("plotting is out of scope of hommx_amd; use u.x.array with any plotting tool")
+
+
+def _zero_rows_columns(A: sp.csr_matrix, idx: np.ndarray) -> sp.csr_matrix:
+    """PETSc MatZeroRowsColumns(idx, diag=1.0) (hmm.py:478)."""
+    n = A.shape[0]
+    keep = np.ones(n)
+    keep[idx] = 0.0
+    Dk = sp.diags(keep)
+    A = Dk @ A @ Dk
+    return (A + sp.diags(1.0 - keep)).tocsr()
+
+
+def _box_boundary_nodes(msh: Mesh) -> np.ndarray:
+    x = msh.geometry.x[:, : msh.topology.dim]
+    lo, hi = x.min(axis=0), x.max(axis=0)
+    return np.nonzero(np.any(np.isclose(x, lo) | np.isclose(x, hi), axis=1))[0]
+
+
+class PoissonHMM(BaseHMM):
+    """hmm.py:514-667.  Forms: micro LHS :644-647, RHS :649-650, local stiffness :652-667."""
+
+    _kind = "poisson"
+
+    def __init__(self, msh, A, f, msh_micro, eps, petsc_options_global_solve=None, petsc_options_cell_problem=None,
+                 petsc_options_prefix: str = "hommx_PoissonHMM", **kw):
+        super().__init__(msh, A, f, msh_micro, eps, petsc_options_global_solve, petsc_options_cell_problem,
+                         petsc_options_prefix, **kw)
+        # homogeneous Dirichlet on the bounding box by default (hmm.py:598-636)
+        self._bcs = [fem.dirichletbc(0.0, _box_boundary_nodes(self._msh), self._V_macro)]
+
+    def _setup_macro_function_space(self):
+        return fem.functionspace(self._msh, ("Lagrange", 1))
+
+
+class PoissonStratifiedHMM(PoissonHMM):
+    """hmm.py:670-789: ``Dtheta_transpose`` comes right after ``eps`` (hmm.py:717-728); M[i][j] = d theta_j/d x_i."""
+
+    def __init__(self, msh, A, f, msh_micro, eps, Dtheta_transpose, petsc_options_global_solve=None,
+                 petsc_options_cell_problem=None, petsc_options_prefix: str = "hommx_PoissonStratifiedHMM", **kw):
+        super().__init__(msh, A, f, msh_micro, eps, petsc_options_global_solve, petsc_options_cell_problem,
+                         petsc_options_prefix, **kw)
+        self._Dtheta_t = Dtheta_transpose
+
+
+class LinearElasticityHMM(BaseHMM):
+    """hmm.py:792-922.  No boundary condition by default (hmm.py:806-807)."""
+
+    _kind = "elasticity"
+
+    def __init__(self, msh, A, f, msh_micro, eps, petsc_options_global_solve=None, petsc_options_cell_problem=None,
+                 petsc_options_prefix: str = "hommx_LinearElasticityHMM", **kw):
+        super().__init__(msh, A, f, msh_micro, eps, petsc_options_global_solve, petsc_options_cell_problem,
+                         petsc_options_prefix, **kw)
+
+    def _setup_macro_function_space(self):
+        return fem.functionspace(self._msh, ("Lagrange", 1, (self._tdim,)))
+
+
+class LinearElasticityStratifiedHMM(LinearElasticityHMM):
+    """hmm.py:925-1067: e_D(u) = sym(Dtheta^T . nabla_grad u) (:1024-1030)."""
+
+    def __init__(self, msh, A, f, msh_micro, eps, Dtheta_transpose, petsc_options_global_solve=None,
+                 petsc_options_cell_problem=None, petsc_options_prefix: str = "hommx_LinearElasticityHMM", **kw):
+        super().__init__(msh, A, f, msh_micro, eps, petsc_options_global_solve, petsc_options_cell_problem,
+                         petsc_options_prefix, **kw)
+        self._Dtheta_t = Dtheta_transpose
+
+
+class PoissonPeriodicHMM:
+    """Classical periodic homogenisation, A = A(y) (hmm.py:1070-1279): one cell problem -> constant A_hom -> plain FEM
+    macro solve.  ``compute_effective_tensor`` (hmm.py:1219-1245) is a batch of ONE on the GPU."""
+
+    def __init__(self, msh, A, f, msh_micro, eps, petsc_options_global_solve=None, petsc_options_cell_problem=None,
+                 petsc_options_prefix: str = "hommx_periodicHMM", **kw):
+        self._inner = PoissonHMM(msh, lambda x, y: A(y), f, msh_micro, eps, petsc_options_global_solve,
+                                 petsc_options_cell_problem, petsc_options_prefix, **kw)
+        self._inner._bcs = []
+        self._A_hom = None
+
+    @property
+    def function_space(self):
+        return self._inner.function_space
+
+    @property
+    def A_hom(self):
+        return self._A_hom
+
+    def set_boundary_conditions(self, bcs):
+        self._inner.set_boundary_conditions(bcs)
+
+    def set_right_hand_side(self, f):
+        self._inner.set_right_hand_side(f)
+
+    def compute_effective_tensor(self) -> np.ndarray:
+        AH, info = self._inner._effective_tensors(np.array([0]))
+        if info[0]:
+            self._inner._logger.error("Something went wrong in the cell problem solving for the periodic cell")
+        self._A_hom = AH[0]
+        return self._A_hom
+
+    def solve(self) -> fem.Function:
+        """hmm.py:1247-1256: standard P1 FEM with the constant A_hom."""
+        if self._A_hom is None:
+            self.compute_effective_tensor()
+        h = self._inner
+        cells = np.arange(h._msh.num_cells)
+        S = h._local_stiffness_from_tensors(cells, np.broadcast_to(self._A_hom, (len(cells),) + self._A_hom.shape))
+        dofs = h._msh.cells.astype(np.int64)
+        nb = dofs.shape[1]
+        N = h._num_global_dofs
+        h._A = sp.coo_matrix((S.ravel(), (np.repeat(dofs, nb, axis=1).ravel(), np.tile(dofs, (1, nb)).ravel())),
+                             shape=(N, N)).tocsr()
+        h._needs_reassembly = False
+        self._lp_A = h._A
+        return h.solve()
