@@ -1,18 +1,694 @@
-// blocked.hip -- generic block-cyclic path (placeholder until the kernels land: fails loudly).
-#include "kernels.h"
+// blocked.hip -- generic block-cyclic micro-cell path: any dimension (2, 3), any problem kind (scalar / matrix-valued
+// Poisson, isotropic / general elasticity), optional stratification matrix M, any n_micro >= 3.
+//
+// Pipeline per chunk of macro cells (host-orchestrated batched kernels, grid = cells x tiles):
+//   K1  k_assemble / k_c0 : periodic P1 stencil (3^d slots x bs x bs per node), canonical loads, C0
+//                           (hmm.py:644-650 / 759-772 / 891-903 / 1032-1048; periodic map cell_problem.py:38-300)
+//   K2  block-cyclic elimination over node planes, block b = bs * n^(d-1) (padded to Bp = 32 k):
+//           Sinv = S^-1 (recursive Schur-complement inversion: 32x32 in-register sweeps + fp64-MFMA GEMMs)
+//           V = W Sinv ; S_last -= V W^T ; S_next = D_{j+1} - E Sinv E^T ; W_next = -V E^T      (E sparse, from the stencil)
+//           Vr = R Sinv ; G += Vr R^T ; R_last -= Vr W^T ; R_next = P_{j+1} - Vr E^T           (t <= 6 load rows, padded to 16)
+//   K3  k_finalize : A_H = C0 - G   (== the energy functional hmm.py:652-667 / 774-789 / 905-922 / 1050-1067)
+//
+// Unified element kernel: with w_{a,alpha} in R^t the (Voigt-weighted) "strain" of basis function (a, alpha) and Cv the
+// t x t element matrix  E^m : A : E^n :   K = vol w^T Cv w',  B_m = -vol (Cv w)_m,  C0 = sum vol Cv.
+// Poisson is the case bs = 1, w_a = M grad(lambda_a), Cv = A (d x d).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
 #include "../../include/hommx_hip.h"
+#include "kernels.h"
+#include "sweep.h"
+
 namespace hommx {
-struct BlockedWorkspace { int dim, n, kind; };
-static thread_local const char* g_berr = "";
-const char* blocked_last_error() { return g_berr; }
-int blocked_workspace_create(BlockedWorkspace** out, int, int, int) {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Geo {
+  int dim, n, bs, t, kind, ncomp;
+  int nn, npl, b, Bp, nsub, ncode, n_el;
+  int voff[6][4][3];     // corner offset of local vertex a of sub-element s
+  double grad[6][4][3];  // gradient of its P1 basis function on the unit-size cell (h = 1)
+};
+
+static thread_local std::string g_berr;
+const char* blocked_last_error() { return g_berr.c_str(); }
+
+#define BTRY(expr)                                                                       \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      g_berr = std::string(#expr) + ": " + hipGetErrorString(e__);                       \
+      return e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP;                     \
+    }                                                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: assembly
+// ---------------------------------------------------------------------------------------------------------------
+
+// Voigt weights of sym(e_alpha (x) g): diagonal pairs first, then (01)[,(02),(12)] with factor 2 folded in.
+__device__ __forceinline__ void strain_weights(const Geo& G, const double* g, int alpha, double* w) {
+  const int d = G.dim;
+  if (G.bs == 1) {
+    for (int k = 0; k < d; ++k) w[k] = g[k];
+    return;
+  }
+  for (int k = 0; k < d; ++k) w[k] = (k == alpha) ? g[k] : 0.0;
+  int m = d;
+  for (int k = 0; k < d; ++k)
+    for (int l = k + 1; l < d; ++l, ++m) w[m] = (k == alpha ? g[l] : 0.0) + (l == alpha ? g[k] : 0.0);
+}
+
+// t x t element matrix Cv from the coefficient stream
+__device__ __forceinline__ void element_matrix(const Geo& G, const double* c, double* Cv) {
+  const int d = G.dim, t = G.t;
+  for (int i = 0; i < t * t; ++i) Cv[i] = 0.0;
+  if (G.kind == HOMMX_KIND_POISSON_SCALAR) {
+    for (int k = 0; k < d; ++k) Cv[k * t + k] = c[0];
+  } else if (G.kind == HOMMX_KIND_POISSON_MATRIX) {
+    for (int k = 0; k < d; ++k) Cv[k * t + k] = c[k];
+    int m = d;
+    for (int k = 0; k < d; ++k)
+      for (int l = k + 1; l < d; ++l, ++m) Cv[k * t + l] = Cv[l * t + k] = c[m];
+  } else if (G.kind == HOMMX_KIND_ELASTICITY_ISO) {
+    const double lam = c[0], mu = c[1];
+    for (int k = 0; k < d; ++k)
+      for (int l = 0; l < d; ++l) Cv[k * t + l] = lam + (k == l ? 2.0 * mu : 0.0);
+    for (int m = d; m < t; ++m) Cv[m * t + m] = mu;
+  } else {
+    int q = 0;
+    for (int k = 0; k < t; ++k)
+      for (int l = k; l < t; ++l, ++q) Cv[k * t + l] = Cv[l * t + k] = c[q];
+  }
+}
+
+__global__ void k_assemble(Geo G, const double* __restrict__ coef, const double* __restrict__ Mmat,
+                           double* __restrict__ Kst, double* __restrict__ Brhs, long long ncells) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * G.nn) return;
+  const long long cell = idx / G.nn;
+  const int node = (int)(idx % G.nn);
+  const int d = G.dim, n = G.n, bs = G.bs, t = G.t;
+  int pc[3] = {node % n, (node / n) % n, d == 3 ? node / (n * n) : 0};
+  double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (Mmat) {
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) M[i * 3 + j] = Mmat[cell * d * d + i * d + j];
+  }
+  double vol = 1.0;
+  for (int k = 0; k < d; ++k) vol /= n;
+  vol /= (d == 2 ? 2.0 : 6.0);
+  const double* ccell = coef + cell * (long long)G.n_el * G.ncomp;
+  double* Kc = Kst + cell * (long long)G.ncode * bs * bs * G.nn;
+  double* Bc = Brhs + cell * (long long)t * bs * G.nn;
+  const int nv = d + 1;
+  for (int s = 0; s < G.nsub; ++s) {
+    for (int a = 0; a < nv; ++a) {
+      // the cell whose sub-element s has its local vertex a at this node
+      int cc[3];
+      for (int k = 0; k < 3; ++k) cc[k] = 0;
+      for (int k = 0; k < d; ++k) cc[k] = (pc[k] - G.voff[s][a][k] + n) % n;
+      const long long e = (long long)G.nsub * (cc[0] + n * (cc[1] + (long long)n * cc[2])) + s;
+      double Cv[36];
+      element_matrix(G, ccell + e * G.ncomp, Cv);
+      double gt[4][3];  // g~_b = M (n grad_b)
+      for (int b = 0; b < nv; ++b)
+        for (int i = 0; i < d; ++i) {
+          double acc = 0.0;
+          for (int k = 0; k < d; ++k) acc += M[i * 3 + k] * G.grad[s][b][k];
+          gt[b][i] = acc * n;
+        }
+      for (int al = 0; al < bs; ++al) {
+        double w[6], y[6];
+        strain_weights(G, gt[a], al, w);
+        for (int m = 0; m < t; ++m) {
+          double acc = 0.0;
+          for (int q = 0; q < t; ++q) acc += Cv[m * t + q] * w[q];
+          y[m] = vol * acc;
+        }
+        for (int m = 0; m < t; ++m) Bc[((long long)m * bs + al) * G.nn + node] -= y[m];
+        for (int b = 0; b < nv; ++b) {
+          int code = 0, p3 = 1;
+          for (int k = 0; k < d; ++k, p3 *= 3) code += (G.voff[s][b][k] - G.voff[s][a][k] + 1) * p3;
+          for (int be = 0; be < bs; ++be) {
+            double wb[6];
+            strain_weights(G, gt[b], be, wb);
+            double acc = 0.0;
+            for (int m = 0; m < t; ++m) acc += y[m] * wb[m];
+            Kc[(((long long)code * bs + al) * bs + be) * G.nn + node] += acc;
+          }
+        }
+      }
+    }
+  }
+}
+
+// C0[cell][t][t] = sum_e vol Cv_e ; one block per cell
+__global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ coef, double* __restrict__ C0) {
+  const long long cell = blockIdx.x;
+  const int t = G.t, tt = t * t;
+  double acc[36];
+  for (int i = 0; i < tt; ++i) acc[i] = 0.0;
+  const double* ccell = coef + cell * (long long)G.n_el * G.ncomp;
+  for (int e = threadIdx.x; e < G.n_el; e += 256) {
+    double Cv[36];
+    element_matrix(G, ccell + (long long)e * G.ncomp, Cv);
+    for (int i = 0; i < tt; ++i) acc[i] += Cv[i];
+  }
+  __shared__ double red[256];
+  double vol = 1.0;
+  for (int k = 0; k < G.dim; ++k) vol /= G.n;
+  vol /= (G.dim == 2 ? 2.0 : 6.0);
+  for (int i = 0; i < tt; ++i) {
+    red[threadIdx.x] = acc[i];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) C0[cell * tt + i] = red[0] * vol;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stencil <-> dense plane blocks
+// ---------------------------------------------------------------------------------------------------------------
+
+// in-plane neighbour q' of in-plane node q for in-plane code ipc
+__device__ __forceinline__ int plane_neighbour(const Geo& G, int q, int ipc) {
+  const int n = G.n;
+  if (G.dim == 2) {
+    const int o = ipc - 1;
+    return (q + o + n) % n;
+  }
+  const int ox = ipc % 3 - 1, oy = ipc / 3 - 1;
+  const int i = (q % n + ox + n) % n, j = (q / n + oy + n) % n;
+  return i + n * j;
+}
+
+// dst[r][c] += K[(r in plane rowPlane), (c in plane rowPlane + olast)]; optional identity on the padding diagonal
+__global__ void k_scatter_plane(Geo G, const double* __restrict__ Kst, double* __restrict__ dst, long long ncells,
+                                int rowPlane, int olast, int padIdentity) {
+  const int nipc = G.ncode / 3;
+  const long long per = (long long)G.Bp * nipc * G.bs;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  int rem = (int)(idx % per);
+  const int r = rem % G.Bp;
+  rem /= G.Bp;
+  const int ipc = rem % nipc, be = rem / nipc;
+  double* D = dst + cell * (long long)G.Bp * G.Bp;
+  if (r >= G.b) {
+    if (padIdentity && ipc == 0 && be == 0) D[(long long)r * G.Bp + r] = 1.0;
+    return;
+  }
+  const int q = r / G.bs, al = r % G.bs;
+  const int node = q + G.npl * rowPlane;
+  const int code = ipc + (olast + 1) * nipc;
+  const double v = Kst[((cell * G.ncode + code) * G.bs + al) * G.bs * (long long)G.nn + (long long)be * G.nn + node];
+  if (v != 0.0) {
+    const int c = plane_neighbour(G, q, ipc) * G.bs + be;
+    D[(long long)r * G.Bp + c] += v;
+  }
+}
+
+// OUT[k][c] = alpha * sum_{k'} IN[k][k'] E[c][k'],  E = K[(., plane rowPlane), (., plane rowPlane-1)]  (OUT = alpha IN E^T)
+__global__ void k_right_mult_Et(Geo G, const double* __restrict__ Kst, const double* __restrict__ IN,
+                                double* __restrict__ OUT, long long ncells, int nrows, int rowPlane, double alpha) {
+  const long long per = (long long)nrows * G.Bp;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int c = rem % G.Bp, k = rem / G.Bp;
+  double acc = 0.0;
+  if (c < G.b) {
+    const int nipc = G.ncode / 3;
+    const int q = c / G.bs, al = c % G.bs;
+    const int node = q + G.npl * rowPlane;
+    const double* in = IN + cell * per + (long long)k * G.Bp;
+    for (int ipc = 0; ipc < nipc; ++ipc) {
+      const int qn = plane_neighbour(G, q, ipc);
+      for (int be = 0; be < G.bs; ++be) {
+        const double e = Kst[((cell * G.ncode + ipc) * G.bs + al) * G.bs * (long long)G.nn + (long long)be * G.nn + node];
+        acc += in[qn * G.bs + be] * e;
+      }
+    }
+  }
+  OUT[cell * per + (long long)k * G.Bp + c] = alpha * acc;
+}
+
+// OUT[r][c] = alpha * sum_k E[r][k] X[k][c]   (Bp x Bp)
+__global__ void k_left_mult_E(Geo G, const double* __restrict__ Kst, const double* __restrict__ X,
+                              double* __restrict__ OUT, long long ncells, int rowPlane, double alpha) {
+  const long long per = (long long)G.Bp * G.Bp;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int c = rem % G.Bp, r = rem / G.Bp;
+  double acc = 0.0;
+  if (r < G.b) {
+    const int nipc = G.ncode / 3;
+    const int q = r / G.bs, al = r % G.bs;
+    const int node = q + G.npl * rowPlane;
+    const double* x = X + cell * per + c;
+    for (int ipc = 0; ipc < nipc; ++ipc) {
+      const int qn = plane_neighbour(G, q, ipc);
+      for (int be = 0; be < G.bs; ++be) {
+        const double e = Kst[((cell * G.ncode + ipc) * G.bs + al) * G.bs * (long long)G.nn + (long long)be * G.nn + node];
+        acc += e * x[(long long)(qn * G.bs + be) * G.Bp];
+      }
+    }
+  }
+  OUT[cell * per + (long long)r * G.Bp + c] = alpha * acc;
+}
+
+// R[m][c] (+)= B[m][(c in plane)]  (16 x Bp load rows)
+__global__ void k_add_P(Geo G, const double* __restrict__ Brhs, double* __restrict__ R, long long ncells, int plane,
+                        int overwrite) {
+  const long long per = 16ll * G.Bp;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int c = rem % G.Bp, m = rem / G.Bp;
+  double v = 0.0;
+  if (m < G.t && c < G.b) {
+    const int q = c / G.bs, al = c % G.bs;
+    v = Brhs[cell * (long long)G.t * G.bs * G.nn + ((long long)m * G.bs + al) * G.nn + q + G.npl * plane];
+  }
+  if (overwrite) R[idx] = v;
+  else R[idx] += v;
+}
+
+// gauge: drop the bs unknowns of the last node of the last plane (cell_problem.py:349-361: constants are the kernel)
+__global__ void k_pin_last(Geo G, double* __restrict__ Sl, double* __restrict__ Rl, long long ncells) {
+  const long long per = (long long)G.Bp * G.bs;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int x = rem % G.Bp, p = G.b - G.bs + rem / G.Bp;
+  double* S = Sl + cell * (long long)G.Bp * G.Bp;
+  S[(long long)p * G.Bp + x] = (x == p) ? 1.0 : 0.0;
+  S[(long long)x * G.Bp + p] = (x == p) ? 1.0 : 0.0;
+  if (x < 16) Rl[cell * 16ll * G.Bp + (long long)x * G.Bp + p] = 0.0;
+}
+
+__global__ void k_finalize(Geo G, const double* __restrict__ C0, const double* __restrict__ Gm, double* __restrict__ out,
+                           long long ncells) {
+  const int tt = G.t * G.t;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * tt) return;
+  const long long cell = idx / tt;
+  const int m = (int)(idx % tt) / G.t, q = (int)(idx % tt) % G.t;
+  out[idx] = C0[idx] - Gm[cell * 256 + m * 16 + q];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batched fp64 MFMA GEMM:  C = alpha op(A) op(B) + beta C,  64x64 tile per 256-thread workgroup, 32x32 per wave
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GP = 80;  // LDS row pitch (doubles): 160 dwords == 32 mod 64 -> conflict-free ds_read_b64 fragments
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
+                                              long long sA, const double* __restrict__ B, int ldb, long long sB,
+                                              double beta, double* __restrict__ C, int ldc, long long sC) {
+  __shared__ double As[16 * GP];
+  __shared__ double Bs[16 * GP];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const long long cell = blockIdx.z;
+  A += cell * sA;
+  B += cell * sB;
+  C += cell * sC;
+  const int wi0 = 32 * (w >> 1), wj0 = 32 * (w & 1);
+  const int l15 = l & 15, l4 = l >> 4;
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // ---- stage A tile: As[k][i], i in [0,64), k in [0,16)
+    if (!TA) {
+      const int i = tid >> 2, kq = (tid & 3) * 4;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      if (m0 + i < M) {
+        const double* p = A + (long long)(m0 + i) * lda + k0 + kq;
+        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) As[(kq + x) * GP + i] = v[x];
+    } else {
+      const int k = tid >> 4, iq = (tid & 15) * 4;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      if (m0 + iq < M) {
+        const double* p = A + (long long)(k0 + k) * lda + m0 + iq;
+        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) As[k * GP + iq + x] = v[x];
+    }
+    // ---- stage B tile: Bs[k][j]
+    if (!TB) {
+      const int k = tid >> 4, jq = (tid & 15) * 4;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      if (n0 + jq < N) {
+        const double* p = B + (long long)(k0 + k) * ldb + n0 + jq;
+        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) Bs[k * GP + jq + x] = v[x];
+    } else {
+      const int j = tid >> 2, kq = (tid & 3) * 4;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      if (n0 + j < N) {
+        const double* p = B + (long long)(n0 + j) * ldb + k0 + kq;
+        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
+        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) Bs[(kq + x) * GP + j] = v[x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = As[(4 * ks + l4) * GP + wi0 + 16 * a + l15];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[b] = Bs[(4 * ks + l4) * GP + wj0 + 16 * b + l15];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
+        if (row < M && col < N) {
+          double* p = C + (long long)row * ldc + col;
+          double v = alpha * acc[a][b][r];
+          if (beta != 0.0) v += beta * *p;
+          *p = v;
+        }
+      }
+}
+
+// OUT[i][j] = IN[j][i]  (sub-blocks, batched)
+__global__ void k_transpose(int M, int N, const double* __restrict__ IN, int ldi, long long sI, double* __restrict__ OUT,
+                            int ldo, long long sO, long long ncells) {
+  const long long per = (long long)M * N;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int j = rem % N, i = rem / N;
+  OUT[cell * sO + (long long)i * ldo + j] = IN[cell * sI + (long long)j * ldi + i];
+}
+
+// in-place inverse of the NB x NB SPD diagonal sub-block at (off, off): one wavefront per cell
+template <int NB>
+__global__ __launch_bounds__(64) void k_leaf_inverse(double* __restrict__ S, int ld, long long stride, int off,
+                                                     int32_t* __restrict__ info, int stepcode) {
+  constexpr int RPL = Cfg<NB>::RPL;
+  __shared__ alignas(16) double ubuf[NB];
+  __shared__ alignas(16) double wbuf[NB];
+  const long long cell = blockIdx.x;
+  const int l = threadIdx.x, c = l % NB, g = l / NB, r0 = g * RPL;
+  double* P = S + cell * stride + (long long)off * ld + off;
+  double s[RPL];
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) s[i] = P[(long long)(r0 + i) * ld + c];
+  int bad = 0;
+  SweepStep<NB, 0>::run(s, ubuf, wbuf, c, g, r0, bad);
+#pragma unroll
+  for (int i = 0; i < RPL; ++i) P[(long long)(r0 + i) * ld + c] = -s[i];
+  if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------------------
+struct BlockedWorkspace {
+  Geo G;
+  long long chunk = 0;
+  double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
+  double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
+  double *R = nullptr, *Rl = nullptr, *Vr = nullptr, *Gm = nullptr;
+};
+
+static void fill_tables(Geo& G) {
+  static const int tri[2][3][2] = {{{0, 0}, {1, 0}, {1, 1}}, {{0, 0}, {0, 1}, {1, 1}}};
+  static const int vb[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+  static const int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 7, 5}, {0, 5, 7, 4}, {0, 3, 2, 7}, {0, 6, 4, 7}, {0, 2, 6, 7}};
+  const int d = G.dim, nv = d + 1;
+  for (int s = 0; s < G.nsub; ++s) {
+    double X[4][3] = {};
+    for (int a = 0; a < nv; ++a)
+      for (int k = 0; k < 3; ++k) {
+        int o = 0;
+        if (k < d) o = (d == 2) ? tri[s][a][k] : vb[tet[s][a]][k];
+        G.voff[s][a][k] = o;
+        X[a][k] = o;
+      }
+    // gradients: solve [1 X] coefficients; grad_a = column a of inv([1 X])^T rows 1..d  -> use Cramer via small Gauss-Jordan
+    double Aug[4][8] = {};
+    for (int a = 0; a < nv; ++a) {
+      Aug[a][0] = 1.0;
+      for (int k = 0; k < d; ++k) Aug[a][1 + k] = X[a][k];
+      Aug[a][nv + a] = 1.0;
+    }
+    for (int p = 0; p < nv; ++p) {
+      int piv = p;
+      for (int r = p + 1; r < nv; ++r)
+        if (std::fabs(Aug[r][p]) > std::fabs(Aug[piv][p])) piv = r;
+      for (int q = 0; q < 2 * nv; ++q) std::swap(Aug[p][q], Aug[piv][q]);
+      const double dd = Aug[p][p];
+      for (int q = 0; q < 2 * nv; ++q) Aug[p][q] /= dd;
+      for (int r = 0; r < nv; ++r)
+        if (r != p) {
+          const double f = Aug[r][p];
+          for (int q = 0; q < 2 * nv; ++q) Aug[r][q] -= f * Aug[p][q];
+        }
+    }
+    // inverse Minv = Aug[:, nv:], lambda_a(x) = Minv[0][a] + sum_k Minv[1+k][a] x_k
+    for (int a = 0; a < nv; ++a)
+      for (int k = 0; k < 3; ++k) G.grad[s][a][k] = (k < d) ? Aug[1 + k][nv + a] : 0.0;
+  }
+}
+
+int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   *out = nullptr;
-  g_berr = "configuration not implemented yet (only 2D scalar Poisson, 3 <= n_micro <= 32)";
-  return HOMMX_EINVAL;
+  BlockedWorkspace* ws = new BlockedWorkspace();
+  Geo& G = ws->G;
+  G.dim = dim;
+  G.n = n;
+  G.kind = kind;
+  const bool el = kind >= HOMMX_KIND_ELASTICITY_ISO;
+  G.bs = el ? dim : 1;
+  G.t = el ? dim * (dim + 1) / 2 : dim;
+  G.ncomp = kind == HOMMX_KIND_POISSON_SCALAR ? 1
+            : kind == HOMMX_KIND_POISSON_MATRIX ? dim * (dim + 1) / 2
+            : kind == HOMMX_KIND_ELASTICITY_ISO ? 2
+                                                : G.t * (G.t + 1) / 2;
+  G.nn = dim == 2 ? n * n : n * n * n;
+  G.npl = dim == 2 ? n : n * n;
+  G.b = G.bs * G.npl;
+  G.Bp = (G.b + 31) / 32 * 32;
+  G.nsub = dim == 2 ? 2 : 6;
+  G.ncode = dim == 2 ? 9 : 27;
+  G.n_el = G.nsub * G.nn;
+  fill_tables(G);
+  *out = ws;
+  return 0;
 }
-void blocked_workspace_destroy(BlockedWorkspace* ws) { delete ws; }
-int blocked_solve(BlockedWorkspace*, long long, const double*, const double*, double*, int32_t*, hipStream_t) {
-  g_berr = "not implemented";
-  return HOMMX_EINVAL;
+
+static void ws_free(BlockedWorkspace* ws) {
+  double** ptrs[] = {&ws->Kst, &ws->Brhs, &ws->C0, &ws->S, &ws->W, &ws->Sl, &ws->V, &ws->X, &ws->T,
+                     &ws->R,   &ws->Rl,   &ws->Vr, &ws->Gm};
+  for (auto p : ptrs) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  ws->chunk = 0;
 }
+
+void blocked_workspace_destroy(BlockedWorkspace* ws) {
+  if (!ws) return;
+  ws_free(ws);
+  delete ws;
+}
+
+static long long per_cell_bytes(const Geo& G) {
+  const long long mat = (long long)G.Bp * G.Bp;
+  return 8ll * ((long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36 + 6 * mat + 3 * 16ll * G.Bp + 256);
+}
+
+static int ws_reserve(BlockedWorkspace* ws, long long ncells) {
+  const Geo& G = ws->G;
+  double budget_gb = 16.0;
+  if (const char* e = getenv("HOMMX_BLOCKED_MEM_GB")) budget_gb = atof(e);
+  long long chunk = (long long)(budget_gb * 1e9) / per_cell_bytes(G);
+  if (chunk < 1) chunk = 1;
+  if (chunk > 8192) chunk = 8192;
+  if (chunk > ncells) chunk = ncells;
+  if (chunk <= ws->chunk) return 0;
+  ws_free(ws);
+  const long long mat = (long long)G.Bp * G.Bp;
+  BTRY(hipMalloc(&ws->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
+  BTRY(hipMalloc(&ws->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
+  BTRY(hipMalloc(&ws->C0, 8ll * chunk * 36));
+  BTRY(hipMalloc(&ws->S, 8ll * chunk * mat));
+  BTRY(hipMalloc(&ws->W, 8ll * chunk * mat));
+  BTRY(hipMalloc(&ws->Sl, 8ll * chunk * mat));
+  BTRY(hipMalloc(&ws->V, 8ll * chunk * mat));
+  BTRY(hipMalloc(&ws->X, 8ll * chunk * mat));
+  BTRY(hipMalloc(&ws->T, 8ll * chunk * mat));
+  BTRY(hipMalloc(&ws->R, 8ll * chunk * 16 * G.Bp));
+  BTRY(hipMalloc(&ws->Rl, 8ll * chunk * 16 * G.Bp));
+  BTRY(hipMalloc(&ws->Vr, 8ll * chunk * 16 * G.Bp));
+  BTRY(hipMalloc(&ws->Gm, 8ll * chunk * 256));
+  ws->chunk = chunk;
+  return 0;
+}
+
+namespace {
+struct Ctx {
+  BlockedWorkspace* ws;
+  long long nc;
+  hipStream_t st;
+  int32_t* info;
+  int stepcode;
+};
+
+inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + bs - 1) / bs); }
+
+void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
+          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC) {
+  dim3 grid((N + 63) / 64, (M + 63) / 64, (unsigned)c.nc), block(256);
+  if (!ta && !tb)
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+  else if (!ta && tb)
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+  else if (ta && !tb)
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+  else
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+}
+
+// in-place inverse of the SPD diagonal block [off, off+size) of every cell's matrix S (ld = Bp), recursive
+// Schur-complement form; `tmp` points at free scratch (consumed stack-like by the nesting levels)
+void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
+  const Geo& G = c.ws->G;
+  const int ld = G.Bp;
+  const long long sS = (long long)G.Bp * G.Bp;
+  if (size <= 32) {
+    if (size == 32)
+      hipLaunchKernelGGL(k_leaf_inverse<32>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
+    else
+      hipLaunchKernelGGL(k_leaf_inverse<16>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
+    return;
+  }
+  int s1 = (size / 2) / 32 * 32;
+  if (s1 < 32) s1 = 32;
+  const int s2 = size - s1;
+  double* A11 = S + (long long)off * ld + off;
+  double* A21 = S + (long long)(off + s1) * ld + off;
+  double* A12 = S + (long long)off * ld + off + s1;
+  double* A22 = S + (long long)(off + s1) * ld + off + s1;
+  double* Xm = tmp;  // s2 x s1, ld = s1, batch stride sS (scratch matrices are Bp x Bp per cell)
+  invert(c, S, off, s1, tmp);                                                  // A11 <- A11^-1
+  gemm(c, false, false, s2, s1, s1, 1.0, A21, ld, sS, A11, ld, sS, 0.0, Xm, s1, sS);   // Xm = A21 A11^-1
+  gemm(c, false, true, s2, s2, s1, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A22, ld, sS);   // A22 <- A22 - Xm A21^T
+  invert(c, S, off + s1, s2, tmp + (long long)s1 * s2);                        // A22 <- (Schur)^-1
+  gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sS, 0.0, A21, ld, sS);  // A21 <- -T^-1 Xm
+  gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A11, ld, sS);   // A11 <- A11^-1 - Xm^T A21
+  hipLaunchKernelGGL(k_transpose, dim3(nblk(c.nc * (long long)s1 * s2)), dim3(256), 0, c.st, s1, s2, A21, ld, sS, A12, ld,
+                     sS, c.nc);                                                  // A12 <- A21^T
+}
+}  // namespace
+
+int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out,
+                  int32_t* d_info, hipStream_t st) {
+  if (int rc = ws_reserve(ws, ncells)) return rc;
+  const Geo& G = ws->G;
+  const int n = G.n, Bp = G.Bp;
+  const long long mat = (long long)Bp * Bp;
+  if (d_info) BTRY(hipMemsetAsync(d_info, 0, sizeof(int32_t) * ncells, st));
+  for (long long c0 = 0; c0 < ncells; c0 += ws->chunk) {
+    const long long nc = std::min(ws->chunk, ncells - c0);
+    Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
+    const double* coef = d_coef + c0 * G.n_el * G.ncomp;
+    const double* Mm = d_M ? d_M + c0 * G.dim * G.dim : nullptr;
+    // ---- K1
+    BTRY(hipMemsetAsync(ws->Kst, 0, 8ll * nc * G.ncode * G.bs * G.bs * G.nn, st));
+    BTRY(hipMemsetAsync(ws->Brhs, 0, 8ll * nc * G.t * G.bs * G.nn, st));
+    hipLaunchKernelGGL(k_assemble, dim3(nblk(nc * G.nn, 128)), dim3(128), 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc);
+    hipLaunchKernelGGL(k_c0, dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0);
+    // ---- K2 init
+    BTRY(hipMemsetAsync(ws->S, 0, 8ll * nc * mat, st));
+    BTRY(hipMemsetAsync(ws->W, 0, 8ll * nc * mat, st));
+    BTRY(hipMemsetAsync(ws->Sl, 0, 8ll * nc * mat, st));
+    BTRY(hipMemsetAsync(ws->Gm, 0, 8ll * nc * 256, st));
+    const long long scat = nc * (long long)Bp * (G.ncode / 3) * G.bs;
+    hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->S, nc, 0, 0, 1);
+    hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->W, nc, n - 1, +1, 0);
+    hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->Sl, nc, n - 1, 0, 1);
+    hipLaunchKernelGGL(k_add_P, dim3(nblk(nc * 16ll * Bp)), dim3(256), 0, st, G, ws->Brhs, ws->R, nc, 0, 1);
+    hipLaunchKernelGGL(k_add_P, dim3(nblk(nc * 16ll * Bp)), dim3(256), 0, st, G, ws->Brhs, ws->Rl, nc, n - 1, 1);
+    // ---- K2 elimination of planes 0 .. n-2
+    for (int j = 0; j <= n - 2; ++j) {
+      const bool last = (j == n - 2);
+      c.stepcode = j + 1;
+      if (last)  // the last plane couples to plane n-2 through E as well as through the arrow
+        hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->W, nc, n - 1, -1, 0);
+      invert(c, ws->S, 0, Bp, ws->T);                                                                   // S <- S^-1
+      gemm(c, false, false, Bp, Bp, Bp, 1.0, ws->W, Bp, mat, ws->S, Bp, mat, 0.0, ws->V, Bp, mat);      // V = W Sinv
+      gemm(c, false, true, Bp, Bp, Bp, -1.0, ws->V, Bp, mat, ws->W, Bp, mat, 1.0, ws->Sl, Bp, mat);     // S_last -= V W^T
+      gemm(c, false, false, 16, Bp, Bp, 1.0, ws->R, Bp, 16ll * Bp, ws->S, Bp, mat, 0.0, ws->Vr, Bp, 16ll * Bp);   // Vr = R Sinv
+      gemm(c, false, true, 16, 16, Bp, 1.0, ws->Vr, Bp, 16ll * Bp, ws->R, Bp, 16ll * Bp, 1.0, ws->Gm, 16, 256);   // G += Vr R^T
+      gemm(c, false, true, 16, Bp, Bp, -1.0, ws->Vr, Bp, 16ll * Bp, ws->W, Bp, mat, 1.0, ws->Rl, Bp, 16ll * Bp);  // R_last -= Vr W^T
+      if (!last) {
+        hipLaunchKernelGGL(k_right_mult_Et, dim3(nblk(nc * mat)), dim3(256), 0, st, G, ws->Kst, ws->S, ws->X, nc, Bp, j + 1, 1.0);   // X = Sinv E^T
+        hipLaunchKernelGGL(k_left_mult_E, dim3(nblk(nc * mat)), dim3(256), 0, st, G, ws->Kst, ws->X, ws->S, nc, j + 1, -1.0);        // S = -E X
+        hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->S, nc, j + 1, 0, 1);                 // S += D_{j+1}
+        hipLaunchKernelGGL(k_right_mult_Et, dim3(nblk(nc * mat)), dim3(256), 0, st, G, ws->Kst, ws->V, ws->W, nc, Bp, j + 1, -1.0);  // W = -V E^T
+        hipLaunchKernelGGL(k_right_mult_Et, dim3(nblk(nc * 16ll * Bp)), dim3(256), 0, st, G, ws->Kst, ws->Vr, ws->R, nc, 16, j + 1, -1.0);  // R = -Vr E^T
+        hipLaunchKernelGGL(k_add_P, dim3(nblk(nc * 16ll * Bp)), dim3(256), 0, st, G, ws->Brhs, ws->R, nc, j + 1, 0);                 // R += P_{j+1}
+      }
+    }
+    // ---- last plane
+    c.stepcode = n;
+    hipLaunchKernelGGL(k_pin_last, dim3(nblk(nc * (long long)Bp * G.bs)), dim3(256), 0, st, G, ws->Sl, ws->Rl, nc);
+    invert(c, ws->Sl, 0, Bp, ws->T);
+    gemm(c, false, false, 16, Bp, Bp, 1.0, ws->Rl, Bp, 16ll * Bp, ws->Sl, Bp, mat, 0.0, ws->Vr, Bp, 16ll * Bp);
+    gemm(c, false, true, 16, 16, Bp, 1.0, ws->Vr, Bp, 16ll * Bp, ws->Rl, Bp, 16ll * Bp, 1.0, ws->Gm, 16, 256);
+    // ---- K3
+    hipLaunchKernelGGL(k_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, G, ws->C0, ws->Gm, d_out + c0 * G.t * G.t, nc);
+    BTRY(hipGetLastError());
+  }
+  return 0;
+}
+
 }  // namespace hommx

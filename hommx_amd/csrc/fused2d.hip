@@ -29,34 +29,11 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "sweep.h"
 
 namespace hommx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-
-template <int NB>
-struct Cfg {
-  static constexpr int RPL = NB * NB / 64;  // rows per lane in GJ layout
-  static constexpr int CG = 64 / NB;        // lane groups (each owns RPL rows of every column)
-  static constexpr int NT = NB / 16;        // 16x16 tiles per dimension
-  static constexpr int KK = NB / 4;         // k-steps of the 16x16x4 MFMA
-};
-
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// 1/d to ~1 ulp: v_rcp_f64 seed + two Newton steps (operands are well inside the normal range).
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, r, 1.0);
-  r = fma(e, r, r);
-  e = fma(-d, r, 1.0);
-  r = fma(e, r, r);
-  return r;
-}
 
 // LDS matrix index with an XOR swizzle on odd rows (NB = 32) so that b64 accesses whose lanes
 // 0-15 / 16-31 touch consecutive rows fall on disjoint bank halves.
@@ -81,52 +58,6 @@ struct alignas(16) Lds {
   double vrbuf[2][NB];   // Vr' = R N
   double e0[NB];         // E[r][r]
   double e1[NB];         // E[r][r-1]
-};
-
-// Symmetric Gauss-Jordan sweep of the NB x NB SPD matrix held in GJ layout: s <- -s^-1.
-// Fully unrolled over the pivot index so every register index is static.
-template <int NB, int K>
-struct SweepStep {
-  static __device__ __forceinline__ void run(double (&s)[Cfg<NB>::RPL], Lds<NB>& L, int c, int g, int r0,
-                                             int& bad) {
-    constexpr int RPL = Cfg<NB>::RPL;
-    constexpr int gk = K / RPL, ik = K % RPL;
-    const double d = readlane_f64(s[ik], gk * NB + K);
-    bad |= !(d > 0.0);
-    const double pinv = fast_rcp(d);
-    if (g == gk) {
-      const double u = s[ik];
-      L.ubuf[c] = u;
-      L.wbuf[c] = (c == K) ? -pinv : u * pinv;
-    }
-    __syncthreads();
-    const double w = L.wbuf[c];
-    double x[RPL];
-#pragma unroll
-    for (int i = 0; i < RPL; i += 2) {
-      const double2 t = *reinterpret_cast<const double2*>(&L.ubuf[r0 + i]);
-      x[i] = t.x;
-      x[i + 1] = t.y;
-    }
-#pragma unroll
-    for (int i = 0; i < RPL; ++i) s[i] = fma(-x[i], w, s[i]);
-    if (c == K) {  // pivot column: new column k == scaled pivot row (symmetry)
-#pragma unroll
-      for (int i = 0; i < RPL; i += 2) {
-        const double2 t = *reinterpret_cast<const double2*>(&L.wbuf[r0 + i]);
-        s[i] = t.x;
-        s[i + 1] = t.y;
-      }
-    }
-    if (g == gk) s[ik] = w;  // pivot row
-    // no barrier needed here: the next step's ubuf/wbuf stores follow these loads in program order
-    // of the same wave, and the LDS pipeline is in-order per wave
-    SweepStep<NB, K + 1>::run(s, L, c, g, r0, bad);
-  }
-};
-template <int NB>
-struct SweepStep<NB, NB> {
-  static __device__ __forceinline__ void run(double (&)[Cfg<NB>::RPL], Lds<NB>&, int, int, int, int&) {}
 };
 
 template <int NB>
@@ -279,7 +210,7 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
 
     // (1) N = -S^-1
     int badj = 0;
-    SweepStep<NB, 0>::run(s, L, c, g, r0, badj);
+    SweepStep<NB, 0>::run(s, L.ubuf, L.wbuf, c, g, r0, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
 
     // (2) N -> LDS (row r0+i, col c): consecutive lanes -> consecutive addresses
@@ -449,7 +380,7 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
   __syncthreads();
   {
     int badj = 0;
-    SweepStep<NB, 0>::run(s, L, c, g, r0, badj);
+    SweepStep<NB, 0>::run(s, L.ubuf, L.wbuf, c, g, r0, badj);
     if (badj && !bad) { bad = 1; badstep = n; }
     double vr[2] = {0.0, 0.0};
 #pragma unroll
