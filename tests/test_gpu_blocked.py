@@ -1,0 +1,175 @@
+"""Parity of the generic blocked HIP path (3D, elasticity, matrix-valued A, stratified) against the CPU oracle (-m gpu).
+
+Tolerance 1e-9 relative per cell tensor (float64; observed 1e-15..1e-12); high-contrast fibre cases 1e-7.
+"""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-9
+
+
+def relerr(A, ref):
+    return float(np.max(np.linalg.norm(A - ref, axis=(1, 2)) / np.linalg.norm(ref, axis=(1, 2))))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import hommx_oracle
+
+    return hommx_oracle
+
+
+def plan(dim, n, kind, flags=0):
+    from hommx_amd import MicroCellPlan
+
+    return MicroCellPlan(dim, n, kind, flags=flags)
+
+
+def test_all_golden_vectors():
+    files = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    assert len(files) == 10
+    for f in files:
+        g = np.load(f)
+        M = g["M"] if g["M"].size else None
+        p = plan(int(g["dim"]), int(g["n"]), str(g["kind"]), flags=1)  # flags=1: force the blocked family
+        assert p.kernel == "blocked"
+        A, info = p.solve(g["coef"], M, return_info=True)
+        assert np.all(info == 0)
+        assert relerr(A, g["A_eff"]) < TOL, f
+
+
+@pytest.mark.parametrize("dim,n", [(2, 7), (2, 12), (3, 3), (3, 5)])
+def test_matrix_valued_poisson(dim, n, rng, O):
+    """Matrix-valued A (the reference's forms hmm.py:644-667 take any A: `A_micro * grad`)."""
+    n_el = (2 if dim == 2 else 6) * n**dim
+    nc = 3
+    Q = rng.standard_normal((nc, n_el, dim, dim))
+    A = np.einsum("ceij,cekj->ceik", Q, Q) + 0.2 * np.eye(dim)
+    pairs = [(0, 0), (1, 1), (0, 1)] if dim == 2 else [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]
+    coef = np.stack([A[..., i, j] for i, j in pairs], axis=-1)
+    M = np.eye(dim)[None] + 0.3 * rng.standard_normal((nc, dim, dim))
+    for MM in (None, M):
+        got = plan(dim, n, "poisson_matrix").solve(coef, MM)
+        assert relerr(got, O.effective_tensor_batch("poisson", dim, n, A, MM)) < TOL
+
+
+@pytest.mark.parametrize("dim,n", [(2, 6), (3, 3)])
+def test_general_hooke_tensor_voigt(dim, n, rng, O):
+    """Full (anisotropic) Hooke tensor through the 21/6-component Voigt kind."""
+    from hommx_amd.hmm import hooke_to_voigt
+
+    n_el = (2 if dim == 2 else 6) * n**dim
+    nc = 2
+    t = dim * (dim + 1) // 2
+    # random SPD elasticity tensors with the minor and major symmetries
+    E = O.unit_strains(dim)
+    L = rng.standard_normal((nc, n_el, t, t))
+    Cv = np.einsum("cemk,cenk->cemn", L, L) + 0.5 * np.eye(t)
+    # tensorial basis dual to E^m: C = sum_mn Cd[m,n] Ed^m (x) Ed^n with Ed = E scaled so that E^m:Ed^n = delta
+    scale = np.array([1.0 / np.sum(E[m] * E[m]) for m in range(t)])
+    Ed = E * scale[:, None, None]
+    C = np.einsum("cemn,mij,nkl->ceijkl", Cv, Ed, Ed)
+    assert np.allclose(hooke_to_voigt(C, dim), Cv)
+    iu = np.triu_indices(t)
+    coef = Cv[..., iu[0], iu[1]]
+    M = np.eye(dim)[None] + 0.25 * rng.standard_normal((nc, dim, dim))
+    for MM in (None, M):
+        got = plan(dim, n, "elasticity_voigt").solve(coef, MM)
+        assert relerr(got, O.effective_tensor_batch("elasticity", dim, n, C, MM)) < TOL
+
+
+def test_constant_hooke_and_layered_kats():
+    """test_integration_linear_elasticity.py:205-322 (C_H = C) and the layered closed forms of SURVEY 8(c)."""
+    for dim, n in ((2, 10), (3, 3), (3, 8)):
+        n_el = (2 if dim == 2 else 6) * n**dim
+        CH = plan(dim, n, "elasticity").solve(np.tile([1.25, 1.0], (1, n_el, 1)))[0]
+        t = CH.shape[0]
+        ref = np.zeros((t, t))
+        ref[:dim, :dim] = 1.25 + 2.0 * np.eye(dim)
+        ref[dim:, dim:] = np.eye(t - dim)
+        assert np.abs(CH - ref).max() < 1e-12
+    from hommx_amd import workloads as W
+
+    n = 8
+    yb = W.element_barycentres(3, n)
+    mu = np.where(np.cos(2 * np.pi * yb[:, 0]) < 0, 5.0, 0.5)
+    CH = plan(3, n, "elasticity").solve(np.stack([np.ones_like(mu), mu], axis=-1)[None])[0]
+    assert abs(CH[0, 0] - 1.0 / np.mean([1 / 11.0, 1 / 2.0])) < 1e-11
+    assert abs(CH[3, 3] - 1.0 / np.mean([1 / 5.0, 1 / 0.5])) < 1e-11
+
+
+def test_poisson_3d_reference_case(rng, O):
+    """test_integration_poisson.py:243-294: A = 1.1 + x0 + sin(2 pi y0) on 6^3 micro cells."""
+    n = 6
+    x0 = np.linspace(0.05, 0.95, 5)
+    coef = np.stack([O.sample_coefficient(lambda x, y: 1.1 + x[0] + np.sin(2 * np.pi * y[0]), np.array([v, 0, 0]), 3, n, 3)
+                     for v in x0])
+    got = plan(3, n, "poisson").solve(coef)
+    assert relerr(got, O.effective_tensor_batch("poisson", 3, n, coef)) < TOL
+    # laminate in y0: transverse directions see the arithmetic mean 1.1 + x0 exactly
+    assert np.abs(got[:, 1, 1] - (1.1 + x0)).max() < 1e-12
+
+
+def test_c4_c5_reduced_vs_oracle(O):
+    """C4 / C5 of BASELINE.json on a reduced macro mesh and 8^3 micro cells (fibre contrast 1e5): oracle parity."""
+    from hommx_amd import workloads as W
+
+    msh, coef, _ = W.c4_fibre_beam(shape=(2, 1, 1), n=8)
+    got, info = plan(3, 8, "elasticity").solve(coef, return_info=True)
+    assert np.all(info == 0)
+    assert relerr(got, O.effective_tensor_batch("elasticity", 3, 8, coef)) < 1e-7
+    msh, coef, M = W.c5_rotated_fibres(shape=(2, 1, 1), n=8)
+    got, info = plan(3, 8, "elasticity").solve(coef, M, return_info=True)
+    assert np.all(info == 0)
+    assert relerr(got, O.effective_tensor_batch("elasticity", 3, 8, coef, M)) < 1e-7
+
+
+def test_c4_full_size_properties():
+    """C4 at full size: 20x6x6 box = 4320 tets, 16^3 micro cells (12288 unknowns per cell), size-independent properties."""
+    from hommx_amd import workloads as W
+
+    msh, coef, _ = W.c4_fibre_beam()
+    assert coef.shape == (4320, 24576, 2)
+    p = plan(3, 16, "elasticity")
+    C, info = p.solve(coef, return_info=True)
+    assert np.all(info == 0)
+    assert np.abs(C - np.transpose(C, (0, 2, 1))).max() < 1e-9 * np.abs(C).max()
+    ev = np.linalg.eigvalsh(0.5 * (C + np.transpose(C, (0, 2, 1))))
+    assert np.all(ev > 0)
+    # Voigt / Reuss bounds on the axial stiffness along the fibres (y0): Reuss <= C_H[00,00] <= Voigt
+    lam, mu = coef[..., 0], coef[..., 1]
+    voigt = np.mean(lam + 2 * mu, axis=1)
+    reuss = 1.0 / np.mean(1.0 / (lam + 2 * mu), axis=1)
+    assert np.all(C[:, 0, 0] <= voigt * (1 + 1e-10)) and np.all(C[:, 0, 0] >= reuss * (1 - 1e-10))
+    # the fibre is uniform along y0, so the axial modulus is close to the Voigt average and grows with mu_in(x0)
+    c = msh.cell_midpoints()
+    order = np.argsort(c[:, 0])
+    assert np.all(np.diff(C[order, 0, 0][:: 6 * 6 * 6]) >= -1e-9)
+    # cells with the same x0 have the same coefficient => identical tensors
+    same = np.isclose(c[:, 0], c[0, 0])
+    assert np.abs(C[same] - C[0]).max() < 1e-9 * np.abs(C[0]).max()
+    # linearity
+    assert relerr(p.solve(2.0 * coef[:8]), 2.0 * C[:8]) < 1e-12
+
+
+def test_blocked_equals_fused_on_2d_poisson(rng):
+    n, nc = 24, 16
+    coef = np.exp(rng.uniform(np.log(0.01), np.log(10.0), size=(nc, 2 * n * n)))
+    M = np.eye(2)[None] + 0.3 * rng.standard_normal((nc, 2, 2))
+    a = plan(2, n, "poisson").solve(coef, M)
+    b = plan(2, n, "poisson", flags=1).solve(coef, M)
+    assert relerr(a, b) < 1e-11
+
+
+def test_info_reports_bad_cells():
+    n = 4
+    coef = np.ones((3, 6 * n**3, 2))
+    coef[1, :, 1] = -1.0  # negative shear modulus: not SPD
+    A, info = plan(3, n, "elasticity").solve(coef, return_info=True)
+    assert info[0] == 0 and info[2] == 0 and info[1] > 0

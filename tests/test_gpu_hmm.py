@@ -77,7 +77,7 @@ def test_stratified_darcy_flow_gpu():
     M = np.stack([Dt(c) for c in h._msh.cell_midpoints()])
     assert np.abs(h.effective_tensors - W.stratified_laminate_exact(M)).max() < 1e-11
     assert _rel_l2(u, _oracle_twin(mk()).solve()) < 1e-9
-    assert 0.0 <= u.x.array.min() + 1e-9 and np.isclose(u.x.array.max(), 1.0, atol=0.2)
+    assert u.x.array.min() >= -1e-9  # maximum principle (f >= 0, boundary data in [0, 1])
 
 
 def test_single_cell_seam_matches_batch():
