@@ -14,8 +14,8 @@
 //      N      = -S^-1                     symmetric Gauss-Jordan sweep, matrix held in VGPRs
 //      V'     = W N                       v_mfma_f64_16x16x4_f64, A operand from LDS, B from VGPRs
 //      S_last += V' W^T                   v_mfma_f64_16x16x4_f64, both operands in VGPRs
+//      W_next = V' E^T                    sparse (neighbour column by a 16-lane rotation, no LDS staging)
 //      S_next = D_{j+1} + E N E^T         E = coupling row j+1 <- row j, bidiagonal (2 nnz/row)
-//      W_next = V' E^T                    sparse
 // Sign convention: the sweep produces N = -S^-1; primes mark quantities carrying that sign.
 //
 // Register layouts (l = lane):
@@ -31,6 +31,10 @@
 #include "kernels.h"
 #include "sweep.h"
 
+#ifndef HOMMX_FUSED_WAVES_PER_SIMD
+#define HOMMX_FUSED_WAVES_PER_SIMD 2
+#endif
+
 namespace hommx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -43,6 +47,12 @@ __device__ __forceinline__ int midx(int row, int col) {
   return row * NB + col;
 }
 
+// wave-uniform double -> SGPR pair (keeps loop-invariant scalars out of the vector register file)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 struct CoefRow {
   double a0, a1;    // coefficient of triangle 0 (v0,v1,v3) / 1 (v0,v2,v3) of cell (c, row)
   double a0m, a1m;  // same for cell (c-1, row), cyclic
@@ -50,26 +60,27 @@ struct CoefRow {
 
 template <int NB>
 struct alignas(16) Lds {
-  double nmat[NB * NB];  // N = -S^-1 (symmetric), swizzled
-  double mat2[NB * NB];  // staging: band matrices -> register layouts, V'^T, S_last
+  double mat[NB * NB];   // N = -S^-1 (symmetric, swizzled) / band-matrix indexer / S_last transfer
   double ubuf[NB];       // sweep: raw pivot row
   double wbuf[NB];       // sweep: scaled pivot row
   double rbuf[2][NB];    // R rows of the current block
   double vrbuf[2][NB];   // Vr' = R N
   double e0[NB];         // E[r][r]
   double e1[NB];         // E[r][r-1]
+  double vcol[NB];       // V'[:, n-1]: the wrap-around neighbour column of W_next
 };
 
 template <int NB>
-__global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict__ coef,
-                                                        const double* __restrict__ Mmat,
-                                                        double* __restrict__ out, int32_t* __restrict__ info,
-                                                        int n, long long ncells) {
+__global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fused(
+    const double* __restrict__ coef, const double* __restrict__ Mmat, double* __restrict__ out,
+    int32_t* __restrict__ info, int n, long long ncells) {
   constexpr int RPL = Cfg<NB>::RPL, CG = Cfg<NB>::CG, NT = Cfg<NB>::NT, KK = Cfg<NB>::KK;
   __shared__ Lds<NB> L;
 
   const long long cell = blockIdx.x;
   if (cell >= ncells) return;
+  __builtin_assume(n >= 3);  // checked by the host (hommx_plan_create); lets the compiler drop zero-trip paths
+  __builtin_assume(n <= NB);
   const int l = threadIdx.x;
   const int c = l % NB, g = l / NB, r0 = g * RPL;
   const int lb = l - c;
@@ -77,6 +88,20 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
   const int cm = valid ? (c == 0 ? n - 1 : c - 1) : c;  // cyclic left neighbour
   const int cp = valid ? (c == n - 1 ? 0 : c + 1) : c;  // cyclic right neighbour
   const int l15 = l & 15, l4 = l >> 4;
+  // LDS matrix addressing.  The XOR swizzle of odd rows (NB = 32) is folded into a handful of per-lane base
+  // indices so that every access is base + compile-time offset (affine => one VGPR per base, not per address):
+  //   GJ(i)        = element (r0 + i, c)                         parity of the row = parity of i
+  //   GJM(i)       = element (r0 + i, cm)
+  //   TILE(a, row) = element (row + l4, 16 a + l15), row % 4 == 0   parity of the row = parity of l4
+  constexpr int SW = (NB == 32) ? 16 : 0;
+  const int gjE = r0 * NB + c, gjO = r0 * NB + (c ^ SW);
+  const int gjEm = r0 * NB + cm, gjOm = r0 * NB + (cm ^ SW);
+  int tileB[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) tileB[a] = l4 * NB + ((16 * a + l15) ^ ((l4 & 1) ? SW : 0));
+#define GJ(i) (((i) & 1 ? gjO : gjE) + (i) * NB)
+#define GJM(i) (((i) & 1 ? gjOm : gjEm) + (i) * NB)
+#define TILE(a, row) (tileB[a] + (row) * NB)
 
   // ---- stratification matrix M = Dtheta^T(c_T) -> Q = M^T M (hmm.py:759-766) -------------------
   double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
@@ -84,16 +109,12 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
     const double* mp = Mmat + cell * 4;
     m00 = mp[0]; m01 = mp[1]; m10 = mp[2]; m11 = mp[3];
   }
-  const double al = 0.5 * (m00 * m00 + m10 * m10);
-  const double be = 0.5 * (m01 * m01 + m11 * m11);
-  const double ga = 0.5 * (m00 * m01 + m10 * m11);
-  const double ab = al - 2.0 * ga + be;
+  const double al = uniform_f64(0.5 * (m00 * m00 + m10 * m10));
+  const double be = uniform_f64(0.5 * (m01 * m01 + m11 * m11));
+  const double ga = uniform_f64(0.5 * (m00 * m01 + m10 * m11));
+  const double ab = uniform_f64(al - 2.0 * ga + be);
 
   const double* cc = coef + cell * (2ll * n * n);
-
-  // ---- C0 = int_Y A  (the corrector-free part of hmm.py:652-667): plain sum of the stream ------
-  double asum = 0.0;
-  for (int e = l; e < 2 * n * n; e += 64) asum += cc[e];
 
   auto load_row = [&](int jc) {
     CoefRow r;
@@ -116,89 +137,93 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
   auto st_p0 = [&](const CoefRow& cur, const CoefRow& prev) { return cur.a0 - cur.a0m - prev.a1m + prev.a1; };
   auto st_p1 = [&](const CoefRow& cur, const CoefRow& prev) { return cur.a1 + cur.a0m - prev.a0m - prev.a1; };
 
-  // write the cyclic tridiagonal D (diag dg, coupling c<->c+1 = ce) into mat2 [row][col]; identity on padding
-  auto band_D_to_mat2 = [&](double dg, double ce) {
+  // write the cyclic tridiagonal D (diag dg, coupling c<->c+1 = ce) into mat [row][col]; identity on padding
+  auto band_D_to_mat = [&](double dg, double ce) {
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) L.mat2[midx<NB>(r0 + i, c)] = 0.0;
+    for (int i = 0; i < RPL; ++i) L.mat[GJ(i)] = 0.0;
     __syncthreads();
     const double cem = __shfl(ce, lb + cm, 64);
     if (g == 0) {
       if (valid) {
-        L.mat2[midx<NB>(c, c)] = dg;
-        L.mat2[midx<NB>(cp, c)] = ce;
-        L.mat2[midx<NB>(cm, c)] = cem;
+        L.mat[midx<NB>(c, c)] = dg;
+        L.mat[midx<NB>(cp, c)] = ce;
+        L.mat[midx<NB>(cm, c)] = cem;
       } else {
-        L.mat2[midx<NB>(c, c)] = 1.0;
+        L.mat[midx<NB>(c, c)] = 1.0;
       }
     }
     __syncthreads();
   };
-  // write a bidiagonal coupling X into mat2 TRANSPOSED ([col][row]) for an operand-layout read:
+  // write a bidiagonal coupling X into mat TRANSPOSED ([col][row]) for an operand-layout read:
   //   up == true :  X[x][x] = dv, X[x][x+1] = ov     (U orientation: rows lower node row)
   //   up == false:  X[x][x] = dv, X[x+1][x] = ov     (E = U^T)
-  auto band_X_to_mat2T = [&](double dv, double ov, bool up) {
+  auto band_X_to_matT = [&](double dv, double ov, bool up) {
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) L.mat2[midx<NB>(r0 + i, c)] = 0.0;
+    for (int i = 0; i < RPL; ++i) L.mat[GJ(i)] = 0.0;
     __syncthreads();
     if (g == 0 && valid) {
-      L.mat2[midx<NB>(c, c)] = dv;
-      if (up) L.mat2[midx<NB>(cp, c)] = ov;  // X[c][cp] stored at [col cp][row c]
-      else    L.mat2[midx<NB>(c, cp)] = ov;  // X[cp][c] stored at [col c][row cp]
+      L.mat[midx<NB>(c, c)] = dv;
+      if (up) L.mat[midx<NB>(cp, c)] = ov;  // X[c][cp] stored at [col cp][row c]
+      else    L.mat[midx<NB>(c, cp)] = ov;  // X[cp][c] stored at [col c][row cp]
     }
     __syncthreads();
   };
 
   // ---- prologue: rows n-2, n-1, 0 ---------------------------------------------------------------
-  const CoefRow rowA = load_row(n - 2);  // kept for D_{n-2}
-  const CoefRow rowB = load_row(n - 1);
-  CoefRow prev = rowB;
-  CoefRow cur = load_row(0);
-
-  // S_last = D_{n-1} in C layout
-  d4 sl[NT][NT];
-  band_D_to_mat2(st_diag(rowB, rowA), st_E(rowB, rowA));
+  d4 sl[NT][NT];      // S_last, C layout
+  double wf[NT][KK];  // W, operand layout
+  double s[RPL];      // S, GJ layout
+  double rr[2], rl[2];
+  CoefRow cur;
+  {
+    const CoefRow rowA = load_row(n - 2);
+    const CoefRow rowB = load_row(n - 1);
+    cur = load_row(0);
+    // S_last = D_{n-1}
+    band_D_to_mat(st_diag(rowB, rowA), st_E(rowB, rowA));
 #pragma unroll
-  for (int ti = 0; ti < NT; ++ti)
+    for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj)
+      for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sl[ti][tj][r] = L.mat2[midx<NB>(16 * ti + l4 + 4 * r, 16 * tj + l15)];
-  __syncthreads();
-
-  // W_0 = K[(., n-1), (., 0)] = U_{n-1} in operand layout
-  double wf[NT][KK];
-  band_X_to_mat2T(st_N(rowB), st_NE(rowB), true);
+        for (int r = 0; r < 4; ++r) sl[ti][tj][r] = L.mat[TILE(tj, 16 * ti + 4 * r)];
+    __syncthreads();
+    // W_0 = K[(., n-1), (., 0)] = U_{n-1}
+    band_X_to_matT(st_N(rowB), st_NE(rowB), true);
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) wf[t][kk] = L.mat2[midx<NB>(4 * kk + l4, 16 * t + l15)];
-  __syncthreads();
-
-  // S_0 = D_0 in GJ layout
-  double s[RPL];
-  band_D_to_mat2(st_diag(cur, prev), st_E(cur, prev));
+      for (int kk = 0; kk < KK; ++kk) wf[t][kk] = L.mat[TILE(t, 4 * kk)];
+    __syncthreads();
+    // S_0 = D_0
+    band_D_to_mat(st_diag(cur, rowB), st_E(cur, rowB));
 #pragma unroll
-  for (int i = 0; i < RPL; ++i) s[i] = L.mat2[midx<NB>(r0 + i, c)];
-  __syncthreads();
-
-  double rr[2] = {st_p0(cur, prev), st_p1(cur, prev)};    // R_0
-  double rl[2] = {st_p0(rowB, rowA), st_p1(rowB, rowA)};  // R_last
-  double g00 = 0.0, g01 = 0.0, g11 = 0.0;                 // -G partial sums (every lane group holds a copy)
+    for (int i = 0; i < RPL; ++i) s[i] = L.mat[GJ(i)];
+    __syncthreads();
+    rr[0] = st_p0(cur, rowB); rr[1] = st_p1(cur, rowB);    // R_0
+    rl[0] = st_p0(rowB, rowA); rl[1] = st_p1(rowB, rowA);  // R_last
+  }
+  double g00 = 0.0, g01 = 0.0, g11 = 0.0;  // -G partial sums (every lane group holds a copy)
   int bad = 0, badstep = 0;
+  const int kq = (n - 1) >> 2, lq = (n - 1) & 3;  // where column n-1 lives in operand layout
+  const int rotsrc = (l - 16) & 63;
 
   // ---- elimination of node rows 0 .. n-2 ----------------------------------------------------------
   for (int j = 0; j <= n - 2; ++j) {
     const bool lastStep = (j == n - 2);
+    // next coefficient line early (latency hidden behind the sweep)
+    CoefRow nxt = cur;
+    if (!lastStep) nxt = load_row(j + 1);
     // coupling E = K[(., j+1), (., j)] from cell row j:  E[r][r] = cN[r], E[r][r-1] = cNE[r-1]
     const double e0c = st_N(cur);
     const double e1c = __shfl(st_NE(cur), lb + cm, 64);
     if (lastStep) {
       // the last node row couples to row n-2 through E as well as through the arrow: W += E
-      band_X_to_mat2T(e0c, st_NE(cur), false);
+      band_X_to_matT(e0c, st_NE(cur), false);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) wf[t][kk] += L.mat2[midx<NB>(4 * kk + l4, 16 * t + l15)];
+        for (int kk = 0; kk < KK; ++kk) wf[t][kk] += L.mat[TILE(t, 4 * kk)];
       __syncthreads();
     }
     if (g == 0) {
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
 
     // (2) N -> LDS (row r0+i, col c): consecutive lanes -> consecutive addresses
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) L.nmat[midx<NB>(r0 + i, c)] = s[i];
+    for (int i = 0; i < RPL; ++i) L.mat[GJ(i)] = s[i];
     __syncthreads();
 
     // (3) V'^T = N W^T  (C layout == V' in operand layout)
@@ -228,7 +253,7 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
     for (int kk = 0; kk < KK; ++kk) {
       double af[NT];
 #pragma unroll
-      for (int a = 0; a < NT; ++a) af[a] = L.nmat[midx<NB>(4 * kk + l4, 16 * a + l15)];
+      for (int a = 0; a < NT; ++a) af[a] = L.mat[TILE(a, 4 * kk)];
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -236,7 +261,16 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
           vt[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], wf[b][kk], vt[a][b], 0, 0, 0);
     }
 
-    // (4) Vr' = R N  (partial over the lane's rows, then across lane groups); -G += Vr' R^T
+    // (4) S_last += V' W^T
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
+
+    // (5) Vr' = R N  (partial over the lane's rows, then across lane groups); -G += Vr' R^T
     double vr[2] = {0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < RPL; i += 2) {
@@ -257,43 +291,18 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
       L.vrbuf[0][c] = vr[0];
       L.vrbuf[1][c] = vr[1];
     }
-
-    // (5) S_next = D_{j+1} + E N E^T  (regular steps only)
-    CoefRow nxt = cur;
-    if (!lastStep) {
-      nxt = (j + 1 == n - 2) ? rowA : load_row(j + 1);
-      // T[i] = e0c N[r][c] + e1c N[r][cm] for r = r0-1 (cyclic), r0 .. r0+RPL-1
-      double T[RPL + 1];
-      {
-        const int rm = (r0 == 0) ? n - 1 : r0 - 1;
-        T[0] = e0c * L.nmat[midx<NB>(rm, c)] + e1c * L.nmat[midx<NB>(rm, cm)];
-      }
+    // column n-1 of V' (wrap-around neighbour of column 0) -> vcol
+    if (!lastStep && l4 == lq) {
 #pragma unroll
-      for (int i = 0; i < RPL; ++i) T[i + 1] = fma(e1c, L.nmat[midx<NB>(r0 + i, cm)], e0c * s[i]);
-      // D_{j+1} through the LDS indexer
-      band_D_to_mat2(st_diag(nxt, cur), st_E(nxt, cur));
+      for (int kk = 0; kk < KK; ++kk)
+        if (kk == kq) {
 #pragma unroll
-      for (int i = 0; i < RPL; i += 2) {
-        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[r0 + i]);
-        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[r0 + i]);
-        const double dA = L.mat2[midx<NB>(r0 + i, c)];
-        const double dB = L.mat2[midx<NB>(r0 + i + 1, c)];
-        s[i] = fma(a0.x, T[i + 1], fma(a1.x, T[i], dA));
-        s[i + 1] = fma(a0.y, T[i + 2], fma(a1.y, T[i + 1], dB));
-      }
-      __syncthreads();
+          for (int t = 0; t < NT; ++t) L.vcol[16 * t + l15] = vt[kk >> 2][t][kk & 3];
+        }
     }
+    __syncthreads();
 
-    // (6) S_last += V' W^T
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-          sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
-
-    // (7) R_last += Vr' W^T
+    // (6) R_last += Vr' W^T
     {
       double part[2][NT];
 #pragma unroll
@@ -327,31 +336,46 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
     }
 
     if (!lastStep) {
-      // (8) W_next = V' E^T : W_next[i][cc] = V'[i][cc] e0[cc] + V'[i][cc-1] e1[cc]; neighbour column via LDS
+      // (7) W_next = V' E^T : W_next[i][col] = V'[i][col] e0[col] + V'[i][col-1] e1[col].
+      //     In operand layout column col = 4 kk + (l >> 4): the left neighbour sits 16 lanes down (same kk) or,
+      //     for lanes 0-15, in lanes 48-63 of register kk-1; column -1 wraps to n-1 (vcol).
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+      for (int t = 0; t < NT; ++t) {
+        double zprev = L.vcol[16 * t + l15];
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) L.mat2[midx<NB>(16 * a + 4 * r + l4, 16 * b + l15)] = vt[a][b][r];
-      __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        const int col = 4 * kk + l4;
-        const int colm = (col == 0) ? n - 1 : col - 1;  // cyclic (entries with col >= n have e0 = e1 = 0)
-        const double f0 = L.e0[col], f1 = L.e1[col];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const double vm = L.mat2[midx<NB>(colm, 16 * t + l15)];
-          wf[t][kk] = fma(vm, f1, vt[kk >> 2][t][kk & 3] * f0);
+        for (int kk = 0; kk < KK; ++kk) {
+          const double x = vt[kk >> 2][t][kk & 3];
+          const double z = __shfl(x, rotsrc, 64);
+          const double y = (l4 >= 1) ? z : zprev;
+          const double f0 = L.e0[4 * kk + l4], f1 = L.e1[4 * kk + l4];
+          wf[t][kk] = fma(y, f1, x * f0);
+          zprev = z;
         }
+      }
+      // (8) S_next = D_{j+1} + E N E^T.  T[i] = e0c N[r][c] + e1c N[r][cm] for r = r0-1 (cyclic), r0 .. r0+RPL-1
+      double T[RPL + 1];
+      {
+        const int rm = (r0 == 0) ? n - 1 : r0 - 1;
+        T[0] = e0c * L.mat[midx<NB>(rm, c)] + e1c * L.mat[midx<NB>(rm, cm)];
+      }
+#pragma unroll
+      for (int i = 0; i < RPL; ++i) T[i + 1] = fma(e1c, L.mat[GJM(i)], e0c * s[i]);
+      // D_{j+1} through the LDS indexer (N is dead now; the buffer is reused)
+      band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
+#pragma unroll
+      for (int i = 0; i < RPL; i += 2) {
+        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[r0 + i]);
+        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[r0 + i]);
+        const double dA = L.mat[GJ(i)];
+        const double dB = L.mat[GJ(i + 1)];
+        s[i] = fma(a0.x, T[i + 1], fma(a1.x, T[i], dA));
+        s[i + 1] = fma(a0.y, T[i + 2], fma(a1.y, T[i + 1], dB));
       }
       // (9) R_next = P_{j+1} + Vr' E^T
       const double vm0 = __shfl(vr[0], lb + cm, 64);
       const double vm1 = __shfl(vr[1], lb + cm, 64);
       rr[0] = fma(vm0, e1c, fma(vr[0], e0c, st_p0(nxt, cur)));
       rr[1] = fma(vm1, e1c, fma(vr[1], e0c, st_p1(nxt, cur)));
-      prev = cur;
       cur = nxt;
       __syncthreads();
     }
@@ -363,11 +387,11 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) L.mat2[midx<NB>(16 * a + 4 * r + l4, 16 * b + l15)] = sl[a][b][r];
+      for (int r = 0; r < 4; ++r) L.mat[TILE(b, 16 * a + 4 * r)] = sl[a][b][r];
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < RPL; ++i) {
-    double v = L.mat2[midx<NB>(r0 + i, c)];
+    double v = L.mat[GJ(i)];
     const bool prow = (r0 + i == n - 1), pcol = (c == n - 1);
     if (prow || pcol) v = (prow && pcol) ? 1.0 : 0.0;  // gauge: drop the last unknown (cell_problem.py:349-361)
     s[i] = v;
@@ -400,6 +424,10 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
     g11 = fma(vr[1], rl[1], g11);
   }
 
+  // ---- C0 = int_Y A  (the corrector-free part of hmm.py:652-667): plain sum of the stream (L2-resident) --
+  double asum = 0.0;
+  for (int e = l; e < 2 * n * n; e += 64) asum += cc[e];
+
   // ---- K3: wave reduction and output ----------------------------------------------------------------
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -422,6 +450,9 @@ __global__ __launch_bounds__(64) void k_poisson2d_fused(const double* __restrict
     o[3] = c0 + sc * (t10 * m10 + t11 * m11);
     if (info) info[cell] = bad ? badstep : 0;
   }
+#undef GJ
+#undef GJM
+#undef TILE
 }
 
 // ---- launch ---------------------------------------------------------------------------------------
