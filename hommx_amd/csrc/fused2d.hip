@@ -34,6 +34,9 @@
 #ifndef HOMMX_FUSED_WAVES_PER_SIMD
 #define HOMMX_FUSED_WAVES_PER_SIMD 2
 #endif
+#ifndef HOMMX_FUSED_PARK_W
+#define HOMMX_FUSED_PARK_W 1
+#endif
 
 namespace hommx {
 
@@ -233,10 +236,26 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       L.e1[c] = e1c;
     }
 
-    // (1) N = -S^-1
+    // (1) N = -S^-1.  The matrix buffer is idle during the sweep: W is parked there (own lane's slots, no
+    //     cross-lane traffic) so that its 2*NT*KK registers are free while the sweep holds S and the pivot row.
+#if HOMMX_FUSED_PARK_W
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) L.mat[(t * KK + kk) * 64 + l] = wf[t][kk];
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     int badj = 0;
     SweepStep<NB, 0>::run(s, L.ubuf, L.wbuf, c, g, r0, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
+#if HOMMX_FUSED_PARK_W
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) wf[t][kk] = L.mat[(t * KK + kk) * 64 + l];
+    __syncthreads();
+#endif
 
     // (2) N -> LDS (row r0+i, col c): consecutive lanes -> consecutive addresses
 #pragma unroll
@@ -352,24 +371,35 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           zprev = z;
         }
       }
-      // (8) S_next = D_{j+1} + E N E^T.  T[i] = e0c N[r][c] + e1c N[r][cm] for r = r0-1 (cyclic), r0 .. r0+RPL-1
-      double T[RPL + 1];
+      // (8) S_next = D_{j+1} + E N E^T, in place and in chunks of 4 rows (bounds the loads in flight, i.e. the
+      //     live registers).  Pass 1: s[i] <- T(r0+i) = e0c N[r][c] + e1c N[r][cm];  tm1 = T(r0-1) (cyclic).
+      double tm1;
       {
         const int rm = (r0 == 0) ? n - 1 : r0 - 1;
-        T[0] = e0c * L.mat[midx<NB>(rm, c)] + e1c * L.mat[midx<NB>(rm, cm)];
+        tm1 = e0c * L.mat[midx<NB>(rm, c)] + e1c * L.mat[midx<NB>(rm, cm)];
       }
 #pragma unroll
-      for (int i = 0; i < RPL; ++i) T[i + 1] = fma(e1c, L.mat[GJM(i)], e0c * s[i]);
+      for (int i0 = 0; i0 < RPL; i0 += 4) {
+#pragma unroll
+        for (int i = i0; i < i0 + 4; ++i) s[i] = fma(e1c, L.mat[GJM(i)], e0c * s[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // D_{j+1} through the LDS indexer (N is dead now; the buffer is reused)
       band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
+      //     Pass 2 (descending, so that T(r-1) is still intact): s[i] <- D[r][c] + e0[r] T(r) + e1[r] T(r-1)
 #pragma unroll
-      for (int i = 0; i < RPL; i += 2) {
-        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[r0 + i]);
-        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[r0 + i]);
-        const double dA = L.mat[GJ(i)];
-        const double dB = L.mat[GJ(i + 1)];
-        s[i] = fma(a0.x, T[i + 1], fma(a1.x, T[i], dA));
-        s[i + 1] = fma(a0.y, T[i + 2], fma(a1.y, T[i + 1], dB));
+      for (int i0 = RPL - 4; i0 >= 0; i0 -= 4) {
+        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[r0 + i0]);
+        const double2 a0b = *reinterpret_cast<const double2*>(&L.e0[r0 + i0 + 2]);
+        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[r0 + i0]);
+        const double2 a1b = *reinterpret_cast<const double2*>(&L.e1[r0 + i0 + 2]);
+        const double d0 = L.mat[GJ(i0)], d1 = L.mat[GJ(i0 + 1)], d2 = L.mat[GJ(i0 + 2)], d3 = L.mat[GJ(i0 + 3)];
+        const double tlow = (i0 == 0) ? tm1 : s[i0 > 0 ? i0 - 1 : 0];
+        s[i0 + 3] = fma(a0b.y, s[i0 + 3], fma(a1b.y, s[i0 + 2], d3));
+        s[i0 + 2] = fma(a0b.x, s[i0 + 2], fma(a1b.x, s[i0 + 1], d2));
+        s[i0 + 1] = fma(a0.y, s[i0 + 1], fma(a1.y, s[i0], d1));
+        s[i0] = fma(a0.x, s[i0], fma(a1.x, tlow, d0));
+        __builtin_amdgcn_sched_barrier(0);
       }
       // (9) R_next = P_{j+1} + Vr' E^T
       const double vm0 = __shfl(vr[0], lb + cm, 64);
