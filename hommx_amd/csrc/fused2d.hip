@@ -245,9 +245,11 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       for (int kk = 0; kk < KK; ++kk) L.mat[(t * KK + kk) * 64 + l] = wf[t][kk];
     __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifndef HOMMX_ABLATE_SWEEP
     int badj = 0;
     SweepStep<NB, 0>::run(s, L.ubuf, L.wbuf, c, g, r0, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
+#endif
 #if HOMMX_FUSED_PARK_W
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           vt[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], wf[b][kk], vt[a][b], 0, 0, 0);
     }
 
+#ifndef HOMMX_ABLATE_GEMM2
     // (4) S_last += V' W^T
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
         for (int b = 0; b < NT; ++b)
           sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
 
+#endif
     // (5) Vr' = R N  (partial over the lane's rows, then across lane groups); -G += Vr' R^T
     double vr[2] = {0.0, 0.0};
 #pragma unroll
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     }
     __syncthreads();
 
+#ifndef HOMMX_ABLATE_RL
     // (6) R_last += Vr' W^T
     {
       double part[2][NT];
@@ -354,7 +359,9 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       }
     }
 
+#endif
     if (!lastStep) {
+#ifndef HOMMX_ABLATE_WNEXT
       // (7) W_next = V' E^T : W_next[i][col] = V'[i][col] e0[col] + V'[i][col-1] e1[col].
       //     In operand layout column col = 4 kk + (l >> 4): the left neighbour sits 16 lanes down (same kk) or,
       //     for lanes 0-15, in lanes 48-63 of register kk-1; column -1 wraps to n-1 (vcol).
@@ -371,6 +378,8 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           zprev = z;
         }
       }
+#endif
+#ifndef HOMMX_ABLATE_SNEXT
       // (8) S_next = D_{j+1} + E N E^T, in place and in chunks of 4 rows (bounds the loads in flight, i.e. the
       //     live registers).  Pass 1: s[i] <- T(r0+i) = e0c N[r][c] + e1c N[r][cm];  tm1 = T(r0-1) (cyclic).
       double tm1;
@@ -401,6 +410,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
         s[i0] = fma(a0.x, s[i0], fma(a1.x, tlow, d0));
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
       // (9) R_next = P_{j+1} + Vr' E^T
       const double vm0 = __shfl(vr[0], lb + cm, 64);
       const double vm1 = __shfl(vr[1], lb + cm, 64);
