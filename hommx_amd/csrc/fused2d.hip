@@ -71,6 +71,7 @@ struct alignas(16) Lds {
   double e0[NB];         // E[r][r]
   double e1[NB];         // E[r][r-1]
   double vcol[NB];       // V'[:, n-1]: the wrap-around neighbour column of W_next
+  double slbuf[NB * NB]; // S_last accumulators parked between two S_last updates (lane-private slots)
 };
 
 template <int NB>
@@ -173,7 +174,6 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   };
 
   // ---- prologue: rows n-2, n-1, 0 ---------------------------------------------------------------
-  d4 sl[NT][NT];      // S_last, C layout
   double wf[NT][KK];  // W, operand layout
   double s[RPL];      // S, GJ layout
   double rr[2], rl[2];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sl[ti][tj][r] = L.mat[TILE(tj, 16 * ti + 4 * r)];
+        for (int r = 0; r < 4; ++r) L.slbuf[((ti * NT + tj) * 4 + r) * 64 + l] = L.mat[TILE(tj, 16 * ti + 4 * r)];
     __syncthreads();
     // W_0 = K[(., n-1), (., 0)] = U_{n-1}
     band_X_to_matT(st_N(rowB), st_NE(rowB), true);
@@ -283,14 +283,29 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     }
 
 #ifndef HOMMX_ABLATE_GEMM2
-    // (4) S_last += V' W^T
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
+    // (4) S_last += V' W^T.  The accumulators (C layout) live in lane-private LDS slots between two updates.
+    {
+      d4 sl[NT][NT];
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b)
-          sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sl[a][b][r] = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b)
+            sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L.slbuf[((a * NT + b) * 4 + r) * 64 + l] = sl[a][b][r];
+    }
 
 #endif
     // (5) Vr' = R N  (partial over the lane's rows, then across lane groups); -G += Vr' R^T
@@ -353,9 +368,8 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       // lane column c = 16*(c>>4) + (l&15): pick tile t = c >> 4
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        double add = part[m][0];
-        if (NT == 2) add = (c & 16) ? part[m][NT - 1] : part[m][0];
-        rl[m] += add;
+        const double p0 = part[m][0], p1 = part[m][NT - 1];
+        rl[m] += (NT == 2 && (c & 16)) ? p1 : p0;
       }
     }
 
@@ -365,17 +379,27 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       // (7) W_next = V' E^T : W_next[i][col] = V'[i][col] e0[col] + V'[i][col-1] e1[col].
       //     In operand layout column col = 4 kk + (l >> 4): the left neighbour sits 16 lanes down (same kk) or,
       //     for lanes 0-15, in lanes 48-63 of register kk-1; column -1 wraps to n-1 (vcol).
+      int rot = rotsrc;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         double zprev = L.vcol[16 * t + l15];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          const double x = vt[kk >> 2][t][kk & 3];
-          const double z = __shfl(x, rotsrc, 64);
-          const double y = (l4 >= 1) ? z : zprev;
-          const double f0 = L.e0[4 * kk + l4], f1 = L.e1[4 * kk + l4];
-          wf[t][kk] = fma(y, f1, x * f0);
-          zprev = z;
+        for (int k4 = 0; k4 < KK; k4 += 4) {
+          // four columns per batch; the shuffle index of the next batch is made to depend (through an empty asm)
+          // on this batch's last result, so that at most 8 ds_bpermute results are live at a time
+          double z[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] = __shfl(vt[(k4 + q) >> 2][t][(k4 + q) & 3], rot, 64);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kk = k4 + q;
+            const double x = vt[kk >> 2][t][kk & 3];
+            const double y = (l4 >= 1) ? z[q] : zprev;
+            const double f0 = L.e0[4 * kk + l4], f1 = L.e1[4 * kk + l4];
+            wf[t][kk] = fma(y, f1, x * f0);
+            zprev = z[q];
+          }
+          asm volatile("" : "+v"(rot) : "v"(__double2loint(wf[t][k4 + 3])));
         }
       }
 #endif
@@ -387,28 +411,33 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
         const int rm = (r0 == 0) ? n - 1 : r0 - 1;
         tm1 = e0c * L.mat[midx<NB>(rm, c)] + e1c * L.mat[midx<NB>(rm, cm)];
       }
+      {
+        int gm0 = gjEm, gm1 = gjOm;  // chained through an empty asm: at most 4 loads of this pass in flight
 #pragma unroll
-      for (int i0 = 0; i0 < RPL; i0 += 4) {
+        for (int i0 = 0; i0 < RPL; i0 += 4) {
 #pragma unroll
-        for (int i = i0; i < i0 + 4; ++i) s[i] = fma(e1c, L.mat[GJM(i)], e0c * s[i]);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int i = i0; i < i0 + 4; ++i) s[i] = fma(e1c, L.mat[((i & 1) ? gm1 : gm0) + i * NB], e0c * s[i]);
+          asm volatile("" : "+v"(gm0), "+v"(gm1) : "v"(__double2loint(s[i0 + 3])));
+        }
       }
       // D_{j+1} through the LDS indexer (N is dead now; the buffer is reused)
       band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
       //     Pass 2 (descending, so that T(r-1) is still intact): s[i] <- D[r][c] + e0[r] T(r) + e1[r] T(r-1)
+      int gE2 = gjE, gO2 = gjO, eoff = r0;
 #pragma unroll
       for (int i0 = RPL - 4; i0 >= 0; i0 -= 4) {
-        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[r0 + i0]);
-        const double2 a0b = *reinterpret_cast<const double2*>(&L.e0[r0 + i0 + 2]);
-        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[r0 + i0]);
-        const double2 a1b = *reinterpret_cast<const double2*>(&L.e1[r0 + i0 + 2]);
-        const double d0 = L.mat[GJ(i0)], d1 = L.mat[GJ(i0 + 1)], d2 = L.mat[GJ(i0 + 2)], d3 = L.mat[GJ(i0 + 3)];
+        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[eoff + i0]);
+        const double2 a0b = *reinterpret_cast<const double2*>(&L.e0[eoff + i0 + 2]);
+        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[eoff + i0]);
+        const double2 a1b = *reinterpret_cast<const double2*>(&L.e1[eoff + i0 + 2]);
+        const double d0 = L.mat[gE2 + i0 * NB], d1 = L.mat[gO2 + (i0 + 1) * NB];
+        const double d2 = L.mat[gE2 + (i0 + 2) * NB], d3 = L.mat[gO2 + (i0 + 3) * NB];
         const double tlow = (i0 == 0) ? tm1 : s[i0 > 0 ? i0 - 1 : 0];
         s[i0 + 3] = fma(a0b.y, s[i0 + 3], fma(a1b.y, s[i0 + 2], d3));
         s[i0 + 2] = fma(a0b.x, s[i0 + 2], fma(a1b.x, s[i0 + 1], d2));
         s[i0 + 1] = fma(a0.y, s[i0 + 1], fma(a1.y, s[i0], d1));
         s[i0] = fma(a0.x, s[i0], fma(a1.x, tlow, d0));
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(gE2), "+v"(gO2), "+v"(eoff) : "v"(__double2loint(s[i0])));
       }
 #endif
       // (9) R_next = P_{j+1} + Vr' E^T
@@ -427,7 +456,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) L.mat[TILE(b, 16 * a + 4 * r)] = sl[a][b][r];
+      for (int r = 0; r < 4; ++r) L.mat[TILE(b, 16 * a + 4 * r)] = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < RPL; ++i) {
