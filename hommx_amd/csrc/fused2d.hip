@@ -34,6 +34,9 @@
 #ifndef HOMMX_FUSED_WAVES_PER_SIMD
 #define HOMMX_FUSED_WAVES_PER_SIMD 2
 #endif
+#ifndef HOMMX_FUSED_STAGGER
+#define HOMMX_FUSED_STAGGER 0
+#endif
 #ifndef HOMMX_FUSED_PARK_W
 #define HOMMX_FUSED_PARK_W 1
 #endif
@@ -206,6 +209,18 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     rr[0] = st_p0(cur, rowB); rr[1] = st_p1(cur, rowB);    // R_0
     rl[0] = st_p0(rowB, rowA); rl[1] = st_p1(rowB, rowA);  // R_last
   }
+#if HOMMX_FUSED_STAGGER
+  // The two waves that share a SIMD run the same program; left alone they reach the VALU-bound sweep and the
+  // MFMA-bound products together.  Delaying the odd hardware wave slot by about half a block step puts one
+  // wave's matrix products beside the other's sweep (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+  {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hwid));
+    if (hwid & 1) {
+      for (int q = 0; q < HOMMX_FUSED_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
+    }
+  }
+#endif
   double g00 = 0.0, g01 = 0.0, g11 = 0.0;  // -G partial sums (every lane group holds a copy)
   int bad = 0, badstep = 0;
   const int kq = (n - 1) >> 2, lq = (n - 1) & 3;  // where column n-1 lives in operand layout
