@@ -93,3 +93,64 @@ struct SweepStep<NB, NB, SYNC> {
 };
 
 }  // namespace hommx
+
+namespace hommx {
+
+// ---- same sweep, "BLK layout": lane l owns the BS x BS block (bi = l >> 3, bj = l & 7), BS = NB / 8 ----------
+// Element (r, q) of the block is matrix entry (BS*bi + r, BS*bj + q) and lives in s[r * BS + q].
+// Per pivot a lane needs only BS entries of the pivot row for its rows and BS for its columns (2*BS LDS
+// doubles instead of RPL + 1 in the column-strip layout): the sweep is LDS-bandwidth bound, so this is what
+// sets its speed.  The pivot column needs no LDS at all (BS predicated multiplies).
+template <int NB, int K>
+struct SweepStepBlk {
+  static constexpr int BS = NB / 8;
+  static __device__ __forceinline__ void run(double (&s)[BS * BS], double* __restrict__ ubuf,
+                                             double* __restrict__ wbuf, int bi, int bj, int& bad) {
+    constexpr int kb = K / BS, kr = K % BS;
+    const double d = readlane_f64(s[kr * BS + kr], 9 * kb);  // lane (kb, kb)
+    bad |= !(d > 0.0);
+    const double pinv = fast_rcp(d);
+    if (bi == kb) {  // owners of pivot row K: BS consecutive entries each
+      double u[BS], w[BS];
+#pragma unroll
+      for (int q = 0; q < BS; ++q) {
+        u[q] = s[kr * BS + q];
+        w[q] = u[q] * pinv;
+      }
+      if (bj == kb) w[kr] = -pinv;
+#pragma unroll
+      for (int q = 0; q < BS; q += 2) {
+        *reinterpret_cast<double2*>(&ubuf[BS * bj + q]) = double2{u[q], u[q + 1]};
+        *reinterpret_cast<double2*>(&wbuf[BS * bj + q]) = double2{w[q], w[q + 1]};
+      }
+    }
+    __syncthreads();
+    double ur[BS], wc[BS];
+#pragma unroll
+    for (int q = 0; q < BS; q += 2) {
+      const double2 a = *reinterpret_cast<const double2*>(&ubuf[BS * bi + q]);
+      const double2 b = *reinterpret_cast<const double2*>(&wbuf[BS * bj + q]);
+      ur[q] = a.x; ur[q + 1] = a.y;
+      wc[q] = b.x; wc[q + 1] = b.y;
+    }
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int q = 0; q < BS; ++q) s[r * BS + q] = fma(-ur[r], wc[q], s[r * BS + q]);
+    if (bj == kb) {  // pivot column: new (row, K) = (pivot row entry at that row) / pivot, by symmetry
+#pragma unroll
+      for (int r = 0; r < BS; ++r) s[r * BS + kr] = ur[r] * pinv;
+    }
+    if (bi == kb) {  // pivot row (also fixes (K, K) = -1/pivot)
+#pragma unroll
+      for (int q = 0; q < BS; ++q) s[kr * BS + q] = wc[q];
+    }
+    SweepStepBlk<NB, K + 1>::run(s, ubuf, wbuf, bi, bj, bad);
+  }
+};
+template <int NB>
+struct SweepStepBlk<NB, NB> {
+  static __device__ __forceinline__ void run(double (&)[(NB / 8) * (NB / 8)], double*, double*, int, int, int&) {}
+};
+
+}  // namespace hommx
