@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #endif
 #ifndef HOMMX_ABLATE_SWEEP
     int badj = 0;
-    SweepStepBlk<NB, 0>::run(s, L.ubuf, L.wbuf, bi, bj, badj);
+    sweep_blk<NB>(s, L.ubuf, L.wbuf, bi, bj, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
 #endif
 #if HOMMX_FUSED_PARK_W
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   __syncthreads();
   {
     int badj = 0;
-    SweepStepBlk<NB, 0>::run(s, L.ubuf, L.wbuf, bi, bj, badj);
+    sweep_blk<NB>(s, L.ubuf, L.wbuf, bi, bj, badj);
     if (badj && !bad) { bad = 1; badstep = n; }
 #pragma unroll
     for (int r = 0; r < BS; ++r)

@@ -104,12 +104,13 @@ namespace hommx {
 template <int NB, int K>
 struct SweepStepBlk {
   static constexpr int BS = NB / 8;
+  // `d` / `pinv`: pivot K and its reciprocal, computed by the previous step (software pipelining: the
+  // reciprocal chain of pivot K+1 overlaps the bulk of the rank-1 update of pivot K).
   static __device__ __forceinline__ void run(double (&s)[BS * BS], double* __restrict__ ubuf,
-                                             double* __restrict__ wbuf, int bi, int bj, int& bad) {
+                                             double* __restrict__ wbuf, int bi, int bj, int& bad, double d,
+                                             double pinv) {
     constexpr int kb = K / BS, kr = K % BS;
-    const double d = readlane_f64(s[kr * BS + kr], 9 * kb);  // lane (kb, kb)
     bad |= !(d > 0.0);
-    const double pinv = fast_rcp(d);
     if (bi == kb) {  // owners of pivot row K: BS consecutive entries each
       double u[BS], w[BS];
 #pragma unroll
@@ -133,10 +134,20 @@ struct SweepStepBlk {
       ur[q] = a.x; ur[q + 1] = a.y;
       wc[q] = b.x; wc[q + 1] = b.y;
     }
+    // next pivot first: its update, broadcast and reciprocal start before the rest of the rank-1 update
+    constexpr int K1 = (K + 1 < NB) ? K + 1 : K;
+    constexpr int kb1 = K1 / BS, kr1 = K1 % BS;
+    double dn = 1.0, pn = 1.0;
+    if (K + 1 < NB) {
+      s[kr1 * BS + kr1] = fma(-ur[kr1], wc[kr1], s[kr1 * BS + kr1]);
+      dn = readlane_f64(s[kr1 * BS + kr1], 9 * kb1);
+      pn = fast_rcp(dn);
+    }
 #pragma unroll
     for (int r = 0; r < BS; ++r)
 #pragma unroll
-      for (int q = 0; q < BS; ++q) s[r * BS + q] = fma(-ur[r], wc[q], s[r * BS + q]);
+      for (int q = 0; q < BS; ++q)
+        if (!(K + 1 < NB && r == kr1 && q == kr1)) s[r * BS + q] = fma(-ur[r], wc[q], s[r * BS + q]);
     if (bj == kb) {  // pivot column: new (row, K) = (pivot row entry at that row) / pivot, by symmetry
 #pragma unroll
       for (int r = 0; r < BS; ++r) s[r * BS + kr] = ur[r] * pinv;
@@ -145,12 +156,21 @@ struct SweepStepBlk {
 #pragma unroll
       for (int q = 0; q < BS; ++q) s[kr * BS + q] = wc[q];
     }
-    SweepStepBlk<NB, K + 1>::run(s, ubuf, wbuf, bi, bj, bad);
+    SweepStepBlk<NB, K + 1>::run(s, ubuf, wbuf, bi, bj, bad, dn, pn);
   }
 };
 template <int NB>
 struct SweepStepBlk<NB, NB> {
-  static __device__ __forceinline__ void run(double (&)[(NB / 8) * (NB / 8)], double*, double*, int, int, int&) {}
+  static __device__ __forceinline__ void run(double (&)[(NB / 8) * (NB / 8)], double*, double*, int, int, int&,
+                                             double, double) {}
 };
+
+// entry: pivot 0 and its reciprocal, then the pipelined steps
+template <int NB>
+__device__ __forceinline__ void sweep_blk(double (&s)[(NB / 8) * (NB / 8)], double* ubuf, double* wbuf, int bi,
+                                          int bj, int& bad) {
+  const double d0 = readlane_f64(s[0], 0);
+  SweepStepBlk<NB, 0>::run(s, ubuf, wbuf, bi, bj, bad, d0, fast_rcp(d0));
+}
 
 }  // namespace hommx
