@@ -181,10 +181,14 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   double s[RPL];      // S, GJ layout
   double rr[2], rl[2];
   CoefRow cur;
+  // C0 = int_Y A (the corrector-free part of hmm.py:652-667) is accumulated while the coefficient lines stream by:
+  // rows n-1 and 0 here, rows 1 .. n-2 in the loop -- every line exactly once (every lane group holds a copy).
+  double asum;
   {
     const CoefRow rowA = load_row(n - 2);
     const CoefRow rowB = load_row(n - 1);
     cur = load_row(0);
+    asum = (rowB.a0 + rowB.a1) + (cur.a0 + cur.a1);
     // S_last = D_{n-1}
     band_D_to_mat(st_diag(rowB, rowA), st_E(rowB, rowA));
 #pragma unroll
@@ -231,7 +235,10 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     const bool lastStep = (j == n - 2);
     // next coefficient line early (latency hidden behind the sweep)
     CoefRow nxt = cur;
-    if (!lastStep) nxt = load_row(j + 1);
+    if (!lastStep) {
+      nxt = load_row(j + 1);
+      asum += nxt.a0 + nxt.a1;
+    }
     // coupling E = K[(., j+1), (., j)] from cell row j:  E[r][r] = cN[r], E[r][r-1] = cNE[r-1]
     const double e0c = st_N(cur);
     const double e1c = __shfl(st_NE(cur), lb + cm, 64);
@@ -508,9 +515,6 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     g11 = fma(vr[1], rl[1], g11);
   }
 
-  // ---- C0 = int_Y A  (the corrector-free part of hmm.py:652-667): plain sum of the stream (L2-resident) --
-  double asum = 0.0;
-  for (int e = l; e < 2 * n * n; e += 64) asum += cc[e];
 
   // ---- K3: wave reduction and output ----------------------------------------------------------------
 #pragma unroll
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   if (l == 0) {
     const double h = 1.0 / n;
     const double sc = 0.25 * h * h / CG;  // every lane group accumulated a full copy
-    const double c0 = 0.5 * h * h * asum;
+    const double c0 = 0.5 * h * h * asum / CG;
     // A_H = C0 I + (h^2/4) M Gneg M^T
     const double t00 = m00 * g00 + m01 * g01, t01 = m00 * g01 + m01 * g11;
     const double t10 = m10 * g00 + m11 * g01, t11 = m10 * g01 + m11 * g11;
