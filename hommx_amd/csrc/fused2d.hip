@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #endif
 #ifndef HOMMX_ABLATE_SWEEP
     int badj = 0;
-    SweepStep<NB, 0>::run(s, L.ubuf, L.wbuf, c, g, r0, badj);
+    sweep_strip_pipelined<NB>(s, L.ubuf, L.wbuf, c, g, r0, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
 #endif
 #if HOMMX_FUSED_PARK_W
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   __syncthreads();
   {
     int badj = 0;
-    SweepStep<NB, 0>::run(s, L.ubuf, L.wbuf, c, g, r0, badj);
+    sweep_strip_pipelined<NB>(s, L.ubuf, L.wbuf, c, g, r0, badj);
     if (badj && !bad) { bad = 1; badstep = n; }
     double vr[2] = {0.0, 0.0};
 #pragma unroll

@@ -33,6 +33,13 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
+// Empty volatile asm through which a value is threaded: pins the computation of `v` before this program point.
+__device__ __forceinline__ double pin_here(double v) {
+  int hi = __double2hiint(v), lo = __double2loint(v);
+  asm volatile("" : "+v"(hi), "+v"(lo));
+  return __hiloint2double(hi, lo);
+}
+
 // WSYNC: barrier among the lanes that share ubuf/wbuf.  With one wave per workgroup __syncthreads()
 // lowers to a wait on the LDS counter; kernels with several independent waves per workgroup pass a
 // wave-local fence instead.
@@ -91,6 +98,81 @@ template <int NB, class SYNC>
 struct SweepStep<NB, NB, SYNC> {
   static __device__ __forceinline__ void run(double (&)[Cfg<NB>::RPL], double*, double*, int, int, int, int&) {}
 };
+
+}  // namespace hommx
+
+namespace hommx {
+
+// ---- software-pipelined column-strip sweep ----------------------------------------------------------------
+// Same arithmetic as SweepStep, reordered so that one LDS round trip per pivot is the whole critical path:
+//   * the raw pivot row K+1 is written to LDS as soon as ITS entries are updated (first FMA of step K), i.e. a full
+//     step ahead of its use; the rest of the rank-1 update of step K runs in the shadow of that round trip;
+//   * the reciprocal of pivot K+1 (v_rcp_f64 + two Newton steps, ~8 dependent f64 ops) is started at the same
+//     point and is not needed before the row has come back;
+//   * the pivot column is refreshed by a predicated LDS read whose wait merges with the next step's.
+template <int NB, int K>
+struct SweepStepP {
+  static __device__ __forceinline__ void run(double (&s)[Cfg<NB>::RPL], double* __restrict__ ubuf,
+                                             double* __restrict__ wbuf, int c, int g, int r0, int& bad, double d,
+                                             double pinv) {
+    constexpr int RPL = Cfg<NB>::RPL;
+    constexpr int gk = K / RPL, ik = K % RPL;
+    constexpr bool more = (K + 1 < NB);
+    constexpr int K1 = more ? K + 1 : K;
+    constexpr int gk1 = K1 / RPL, ik1 = K1 % RPL;
+    bad |= !(d > 0.0);
+    __syncthreads();  // pivot row K (written one step ago) and the previous pivot-column refresh have landed
+    const double uc = ubuf[c];
+    double x[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; i += 2) {
+      const double2 t2 = *reinterpret_cast<const double2*>(&ubuf[r0 + i]);
+      x[i] = t2.x;
+      x[i + 1] = t2.y;
+    }
+    const double t = (c == K) ? -pinv : uc * pinv;  // scaled pivot row entry of my column
+    double dn = 1.0, pn = 1.0;
+    if (more) {
+      // pivot row K+1 first: update, publish raw, start its reciprocal
+      double e = fma(-x[ik1], t, s[ik1]);
+      if (c == K) e = x[ik1] * pinv;  // its entry in the pivot column K
+      s[ik1] = e;
+      if (g == gk1) ubuf[c] = e;
+      dn = readlane_f64(e, gk1 * NB + K1);
+      pn = pin_here(fast_rcp(dn));  // keep the reciprocal chain HERE (the compiler would sink it to its first use)
+    }
+#pragma unroll
+    for (int i = 0; i < RPL; ++i)
+      if (!(more && i == ik1)) s[i] = fma(-x[i], t, s[i]);
+    if (g == gk) {
+      wbuf[c] = t;
+      s[ik] = t;  // pivot row
+    }
+    if (c == K) {  // pivot column := scaled pivot row (symmetry); the LDS pipeline is in-order per wave
+#pragma unroll
+      for (int i = 0; i < RPL; i += 2) {
+        const double2 t2 = *reinterpret_cast<const double2*>(&wbuf[r0 + i]);
+        s[i] = t2.x;
+        s[i + 1] = t2.y;
+      }
+    }
+    SweepStepP<NB, K + 1>::run(s, ubuf, wbuf, c, g, r0, bad, dn, pn);
+  }
+};
+template <int NB>
+struct SweepStepP<NB, NB> {
+  static __device__ __forceinline__ void run(double (&)[Cfg<NB>::RPL], double*, double*, int, int, int, int&, double,
+                                             double) {}
+};
+
+template <int NB>
+__device__ __forceinline__ void sweep_strip_pipelined(double (&s)[Cfg<NB>::RPL], double* ubuf, double* wbuf, int c,
+                                                      int g, int r0, int& bad) {
+  if (g == 0) ubuf[c] = s[0];  // raw pivot row 0
+  const double d0 = readlane_f64(s[0], 0);
+  SweepStepP<NB, 0>::run(s, ubuf, wbuf, c, g, r0, bad, d0, fast_rcp(d0));
+  __syncthreads();  // the last pivot-column refresh
+}
 
 }  // namespace hommx
 
