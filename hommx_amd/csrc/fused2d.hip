@@ -19,7 +19,8 @@
 // Sign convention: the sweep produces N = -S^-1; primes mark quantities carrying that sign.
 //
 // Register layouts (l = lane):
-//   "GJ"       lane owns column c = l % NB, rows r0 + i, r0 = (l / NB) * RPL, i < RPL = NB*NB/64
+//   "BLK"      lane owns the BS x BS block (bi = l >> 3, bj = l & 7), BS = NB / 8 (sweep; 2*BS LDS doubles per pivot)
+//   "strip"    lane owns column c = l % NB, rows r0 + i, r0 = (l / NB) * RPL   (only to read N back for R N)
 //   "operand"  wf[t][kk] = W[16 t + (l & 15)][4 kk + (l >> 4)]      (A and B fragments of the f64 MFMA)
 //   "C"        acc[ti][tj][r] = X[16 ti + (l >> 4) + 4 r][16 tj + (l & 15)]  (f64 MFMA accumulator map)
 // The product V'^T = N W^T in C layout IS V' in operand layout, so it feeds the second MFMA chain
@@ -98,17 +99,19 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   // LDS matrix addressing.  The XOR swizzle of odd rows (NB = 32) is folded into a handful of per-lane base
   // indices so that every access is base + compile-time offset (affine => one VGPR per base, not per address):
   //   GJ(i)        = element (r0 + i, c)                         parity of the row = parity of i
-  //   GJM(i)       = element (r0 + i, cm)
   //   TILE(a, row) = element (row + l4, 16 a + l15), row % 4 == 0   parity of the row = parity of l4
   constexpr int SW = (NB == 32) ? 16 : 0;
   const int gjE = r0 * NB + c, gjO = r0 * NB + (c ^ SW);
-  const int gjEm = r0 * NB + cm, gjOm = r0 * NB + (cm ^ SW);
   int tileB[NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a) tileB[a] = l4 * NB + ((16 * a + l15) ^ ((l4 & 1) ? SW : 0));
 #define GJ(i) (((i) & 1 ? gjO : gjE) + (i) * NB)
-#define GJM(i) (((i) & 1 ? gjOm : gjEm) + (i) * NB)
 #define TILE(a, row) (tileB[a] + (row) * NB)
+  //   BLK(r, q)    = element (BS bi + r, BS bj + q)                parity of the row = parity of r (BS is even)
+  constexpr int BS = NB / 8;
+  const int bi = l >> 3, bj = l & 7;
+  const int blkE = BS * bi * NB + BS * bj, blkO = BS * bi * NB + ((BS * bj) ^ SW);
+#define BLK(r, q) (((r) & 1 ? blkO : blkE) + (r) * NB + (q))
 
   // ---- stratification matrix M = Dtheta^T(c_T) -> Q = M^T M (hmm.py:759-766) -------------------
   double m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;
@@ -147,7 +150,9 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   // write the cyclic tridiagonal D (diag dg, coupling c<->c+1 = ce) into mat [row][col]; identity on padding
   auto band_D_to_mat = [&](double dg, double ce) {
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) L.mat[GJ(i)] = 0.0;
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int q = 0; q < BS; q += 2) *reinterpret_cast<double2*>(&L.mat[BLK(r, q)]) = double2{0.0, 0.0};
     __syncthreads();
     const double cem = __shfl(ce, lb + cm, 64);
     if (g == 0) {
@@ -166,7 +171,9 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   //   up == false:  X[x][x] = dv, X[x+1][x] = ov     (E = U^T)
   auto band_X_to_matT = [&](double dv, double ov, bool up) {
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) L.mat[GJ(i)] = 0.0;
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int q = 0; q < BS; q += 2) *reinterpret_cast<double2*>(&L.mat[BLK(r, q)]) = double2{0.0, 0.0};
     __syncthreads();
     if (g == 0 && valid) {
       L.mat[midx<NB>(c, c)] = dv;
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 
   // ---- prologue: rows n-2, n-1, 0 ---------------------------------------------------------------
   double wf[NT][KK];  // W, operand layout
-  double s[RPL];      // S, GJ layout
+  double s[RPL];      // S, BLK layout (RPL == BS * BS)
   double rr[2], rl[2];
   CoefRow cur;
   // C0 = int_Y A (the corrector-free part of hmm.py:652-667) is accumulated while the coefficient lines stream by:
@@ -208,7 +215,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     // S_0 = D_0
     band_D_to_mat(st_diag(cur, rowB), st_E(cur, rowB));
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) s[i] = L.mat[GJ(i)];
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int q = 0; q < BS; q += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&L.mat[BLK(r, q)]);
+        s[r * BS + q] = v.x; s[r * BS + q + 1] = v.y;
+      }
     __syncthreads();
     rr[0] = st_p0(cur, rowB); rr[1] = st_p1(cur, rowB);    // R_0
     rl[0] = st_p0(rowB, rowA); rl[1] = st_p1(rowB, rowA);  // R_last
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #endif
 #ifndef HOMMX_ABLATE_SWEEP
     int badj = 0;
-    sweep_strip_pipelined<NB>(s, L.ubuf, L.wbuf, c, g, r0, badj);
+    sweep_blk<NB>(s, L.ubuf, L.wbuf, bi, bj, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
 #endif
 #if HOMMX_FUSED_PARK_W
@@ -281,9 +293,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     __syncthreads();
 #endif
 
-    // (2) N -> LDS (row r0+i, col c): consecutive lanes -> consecutive addresses
+    // (2) N -> LDS: BS rows of BS consecutive doubles per lane (8 lanes cover one 256-byte matrix row)
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) L.mat[GJ(i)] = s[i];
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int q = 0; q < BS; q += 2)
+        *reinterpret_cast<double2*>(&L.mat[BLK(r, q)]) = double2{s[r * BS + q], s[r * BS + q + 1]};
     __syncthreads();
 
     // (3) V'^T = N W^T  (C layout == V' in operand layout)
@@ -333,11 +348,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     // (5) Vr' = R N  (partial over the lane's rows, then across lane groups); -G += Vr' R^T
     double vr[2] = {0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < RPL; i += 2) {
+    for (int i = 0; i < RPL; i += 2) {  // column strip of N (rows r0 .. r0+RPL-1 of column c) read back from LDS
       const double2 q0 = *reinterpret_cast<const double2*>(&L.rbuf[0][r0 + i]);
       const double2 q1 = *reinterpret_cast<const double2*>(&L.rbuf[1][r0 + i]);
-      vr[0] = fma(q0.x, s[i], vr[0]); vr[0] = fma(q0.y, s[i + 1], vr[0]);
-      vr[1] = fma(q1.x, s[i], vr[1]); vr[1] = fma(q1.y, s[i + 1], vr[1]);
+      const double n0 = L.mat[GJ(i)], n1 = L.mat[GJ(i + 1)];
+      vr[0] = fma(q0.x, n0, vr[0]); vr[0] = fma(q0.y, n1, vr[0]);
+      vr[1] = fma(q1.x, n0, vr[1]); vr[1] = fma(q1.y, n1, vr[1]);
     }
 #pragma unroll
     for (int off = NB; off < 64; off <<= 1) {
@@ -426,40 +442,48 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       }
 #endif
 #ifndef HOMMX_ABLATE_SNEXT
-      // (8) S_next = D_{j+1} + E N E^T, in place and in chunks of 4 rows (bounds the loads in flight, i.e. the
-      //     live registers).  Pass 1: s[i] <- T(r0+i) = e0c N[r][c] + e1c N[r][cm];  tm1 = T(r0-1) (cyclic).
-      double tm1;
+      // (8) S_next = D_{j+1} + E N E^T in BLK layout.  With T(r, q) = e0[col q] N[r][col q] + e1[col q] N[r][col q - 1]:
+      //     S_next[r][q] = D[r][q] + e0[row r] T(r, q) + e1[row r] T(r - 1, q);  row -1 / column -1 are cyclic (n - 1).
       {
-        const int rm = (r0 == 0) ? n - 1 : r0 - 1;
-        tm1 = e0c * L.mat[midx<NB>(rm, c)] + e1c * L.mat[midx<NB>(rm, cm)];
-      }
-      {
-        int gm0 = gjEm, gm1 = gjOm;  // chained through an empty asm: at most 4 loads of this pass in flight
+        const int rowm = (bi == 0) ? n - 1 : BS * bi - 1;
+        const int colm = (bj == 0) ? n - 1 : BS * bj - 1;
+        double e0q[BS], e1q[BS], e0r[BS], e1r[BS];
 #pragma unroll
-        for (int i0 = 0; i0 < RPL; i0 += 4) {
-#pragma unroll
-          for (int i = i0; i < i0 + 4; ++i) s[i] = fma(e1c, L.mat[((i & 1) ? gm1 : gm0) + i * NB], e0c * s[i]);
-          asm volatile("" : "+v"(gm0), "+v"(gm1) : "v"(__double2loint(s[i0 + 3])));
+        for (int q = 0; q < BS; q += 2) {
+          const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[BS * bj + q]);
+          const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[BS * bj + q]);
+          const double2 b0 = *reinterpret_cast<const double2*>(&L.e0[BS * bi + q]);
+          const double2 b1 = *reinterpret_cast<const double2*>(&L.e1[BS * bi + q]);
+          e0q[q] = a0.x; e0q[q + 1] = a0.y; e1q[q] = a1.x; e1q[q + 1] = a1.y;
+          e0r[q] = b0.x; e0r[q + 1] = b0.y; e1r[q] = b1.x; e1r[q + 1] = b1.y;
         }
-      }
-      // D_{j+1} through the LDS indexer (N is dead now; the buffer is reused)
-      band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
-      //     Pass 2 (descending, so that T(r-1) is still intact): s[i] <- D[r][c] + e0[r] T(r) + e1[r] T(r-1)
-      int gE2 = gjE, gO2 = gjO, eoff = r0;
+        // halo of the block: the row above (with its left neighbour) and the column to the left
+        double hup[BS + 1], hleft[BS];
+        hup[0] = L.mat[midx<NB>(rowm, colm)];
 #pragma unroll
-      for (int i0 = RPL - 4; i0 >= 0; i0 -= 4) {
-        const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[eoff + i0]);
-        const double2 a0b = *reinterpret_cast<const double2*>(&L.e0[eoff + i0 + 2]);
-        const double2 a1 = *reinterpret_cast<const double2*>(&L.e1[eoff + i0]);
-        const double2 a1b = *reinterpret_cast<const double2*>(&L.e1[eoff + i0 + 2]);
-        const double d0 = L.mat[gE2 + i0 * NB], d1 = L.mat[gO2 + (i0 + 1) * NB];
-        const double d2 = L.mat[gE2 + (i0 + 2) * NB], d3 = L.mat[gO2 + (i0 + 3) * NB];
-        const double tlow = (i0 == 0) ? tm1 : s[i0 > 0 ? i0 - 1 : 0];
-        s[i0 + 3] = fma(a0b.y, s[i0 + 3], fma(a1b.y, s[i0 + 2], d3));
-        s[i0 + 2] = fma(a0b.x, s[i0 + 2], fma(a1b.x, s[i0 + 1], d2));
-        s[i0 + 1] = fma(a0.y, s[i0 + 1], fma(a1.y, s[i0], d1));
-        s[i0] = fma(a0.x, s[i0], fma(a1.x, tlow, d0));
-        asm volatile("" : "+v"(gE2), "+v"(gO2), "+v"(eoff) : "v"(__double2loint(s[i0])));
+        for (int q = 0; q < BS; ++q) hup[q + 1] = L.mat[midx<NB>(rowm, BS * bj + q)];
+#pragma unroll
+        for (int r = 0; r < BS; ++r) hleft[r] = L.mat[midx<NB>(BS * bi + r, colm)];
+        double Tprev[BS];  // T(r - 1, .)
+#pragma unroll
+        for (int q = 0; q < BS; ++q) Tprev[q] = fma(e1q[q], hup[q], e0q[q] * hup[q + 1]);
+        // D_{j+1} through the LDS indexer (all reads of N are done; the buffer is reused)
+        band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+          double Tcur[BS];
+#pragma unroll
+          for (int q = 0; q < BS; ++q)
+            Tcur[q] = fma(e1q[q], (q == 0) ? hleft[r] : s[r * BS + q - 1], e0q[q] * s[r * BS + q]);
+#pragma unroll
+          for (int q = 0; q < BS; q += 2) {
+            const double2 dd = *reinterpret_cast<const double2*>(&L.mat[BLK(r, q)]);
+            s[r * BS + q] = fma(e0r[r], Tcur[q], fma(e1r[r], Tprev[q], dd.x));
+            s[r * BS + q + 1] = fma(e0r[r], Tcur[q + 1], fma(e1r[r], Tprev[q + 1], dd.y));
+          }
+#pragma unroll
+          for (int q = 0; q < BS; ++q) Tprev[q] = Tcur[q];
+        }
       }
 #endif
       // (9) R_next = P_{j+1} + Vr' E^T
@@ -481,12 +505,14 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       for (int r = 0; r < 4; ++r) L.mat[TILE(b, 16 * a + 4 * r)] = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < RPL; ++i) {
-    double v = L.mat[GJ(i)];
-    const bool prow = (r0 + i == n - 1), pcol = (c == n - 1);
-    if (prow || pcol) v = (prow && pcol) ? 1.0 : 0.0;  // gauge: drop the last unknown (cell_problem.py:349-361)
-    s[i] = v;
-  }
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int q = 0; q < BS; ++q) {
+      double v = L.mat[BLK(r, q)];
+      const bool prow = (BS * bi + r == n - 1), pcol = (BS * bj + q == n - 1);
+      if (prow || pcol) v = (prow && pcol) ? 1.0 : 0.0;  // gauge: drop the last unknown (cell_problem.py:349-361)
+      s[r * BS + q] = v;
+    }
   if (c == n - 1) { rl[0] = 0.0; rl[1] = 0.0; }
   if (g == 0) {
     L.rbuf[0][c] = rl[0];
@@ -495,15 +521,22 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   __syncthreads();
   {
     int badj = 0;
-    sweep_strip_pipelined<NB>(s, L.ubuf, L.wbuf, c, g, r0, badj);
+    sweep_blk<NB>(s, L.ubuf, L.wbuf, bi, bj, badj);
     if (badj && !bad) { bad = 1; badstep = n; }
+#pragma unroll
+    for (int r = 0; r < BS; ++r)
+#pragma unroll
+      for (int q = 0; q < BS; q += 2)
+        *reinterpret_cast<double2*>(&L.mat[BLK(r, q)]) = double2{s[r * BS + q], s[r * BS + q + 1]};
+    __syncthreads();
     double vr[2] = {0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < RPL; i += 2) {
+    for (int i = 0; i < RPL; i += 2) {  // column strip of N (rows r0 .. r0+RPL-1 of column c) read back from LDS
       const double2 q0 = *reinterpret_cast<const double2*>(&L.rbuf[0][r0 + i]);
       const double2 q1 = *reinterpret_cast<const double2*>(&L.rbuf[1][r0 + i]);
-      vr[0] = fma(q0.x, s[i], vr[0]); vr[0] = fma(q0.y, s[i + 1], vr[0]);
-      vr[1] = fma(q1.x, s[i], vr[1]); vr[1] = fma(q1.y, s[i + 1], vr[1]);
+      const double n0 = L.mat[GJ(i)], n1 = L.mat[GJ(i + 1)];
+      vr[0] = fma(q0.x, n0, vr[0]); vr[0] = fma(q0.y, n1, vr[0]);
+      vr[1] = fma(q1.x, n0, vr[1]); vr[1] = fma(q1.y, n1, vr[1]);
     }
 #pragma unroll
     for (int off = NB; off < 64; off <<= 1) {
@@ -539,7 +572,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     if (info) info[cell] = bad ? badstep : 0;
   }
 #undef GJ
-#undef GJM
+#undef BLK
 #undef TILE
 }
 

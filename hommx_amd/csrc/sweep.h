@@ -186,73 +186,81 @@ namespace hommx {
 template <int NB, int K>
 struct SweepStepBlk {
   static constexpr int BS = NB / 8;
-  // `d` / `pinv`: pivot K and its reciprocal, computed by the previous step (software pipelining: the
-  // reciprocal chain of pivot K+1 overlaps the bulk of the rank-1 update of pivot K).
-  static __device__ __forceinline__ void run(double (&s)[BS * BS], double* __restrict__ ubuf,
-                                             double* __restrict__ wbuf, int bi, int bj, int& bad, double d,
-                                             double pinv) {
+  // Entered with the RAW pivot row K already in ubuf (published one step earlier) and `d`, `pinv` = pivot K and
+  // its reciprocal.  Only the raw row goes through LDS (one write of BS doubles by the 8 owner lanes, 2*BS doubles
+  // read per lane); the scaling by 1/pivot is BS + BS multiplies per lane.
+  static __device__ __forceinline__ void run(double (&s)[BS * BS], double* __restrict__ ubuf, int bi, int bj,
+                                             int& bad, double d, double pinv) {
     constexpr int kb = K / BS, kr = K % BS;
+    constexpr bool more = (K + 1 < NB);
+    constexpr int K1 = more ? K + 1 : K;
+    constexpr int kb1 = K1 / BS, kr1 = K1 % BS;
     bad |= !(d > 0.0);
-    if (bi == kb) {  // owners of pivot row K: BS consecutive entries each
-      double u[BS], w[BS];
-#pragma unroll
-      for (int q = 0; q < BS; ++q) {
-        u[q] = s[kr * BS + q];
-        w[q] = u[q] * pinv;
-      }
-      if (bj == kb) w[kr] = -pinv;
-#pragma unroll
-      for (int q = 0; q < BS; q += 2) {
-        *reinterpret_cast<double2*>(&ubuf[BS * bj + q]) = double2{u[q], u[q + 1]};
-        *reinterpret_cast<double2*>(&wbuf[BS * bj + q]) = double2{w[q], w[q + 1]};
-      }
-    }
     __syncthreads();
-    double ur[BS], wc[BS];
+    double ur[BS], uc[BS], t[BS];
 #pragma unroll
     for (int q = 0; q < BS; q += 2) {
       const double2 a = *reinterpret_cast<const double2*>(&ubuf[BS * bi + q]);
-      const double2 b = *reinterpret_cast<const double2*>(&wbuf[BS * bj + q]);
+      const double2 b = *reinterpret_cast<const double2*>(&ubuf[BS * bj + q]);
       ur[q] = a.x; ur[q + 1] = a.y;
-      wc[q] = b.x; wc[q + 1] = b.y;
+      uc[q] = b.x; uc[q + 1] = b.y;
     }
-    // next pivot first: its update, broadcast and reciprocal start before the rest of the rank-1 update
-    constexpr int K1 = (K + 1 < NB) ? K + 1 : K;
-    constexpr int kb1 = K1 / BS, kr1 = K1 % BS;
+#pragma unroll
+    for (int r = 0; r < BS; ++r) t[r] = ur[r] * pinv;  // scaled pivot-row entries at my rows (== new pivot column)
     double dn = 1.0, pn = 1.0;
-    if (K + 1 < NB) {
-      s[kr1 * BS + kr1] = fma(-ur[kr1], wc[kr1], s[kr1 * BS + kr1]);
-      dn = readlane_f64(s[kr1 * BS + kr1], 9 * kb1);
-      pn = fast_rcp(dn);
+    if (more) {
+      // pivot row K+1 first: update its BS entries, fix the one in pivot column K, publish raw, start 1/pivot
+      double e[BS];
+#pragma unroll
+      for (int q = 0; q < BS; ++q) e[q] = fma(-t[kr1], uc[q], s[kr1 * BS + q]);
+      if (bj == kb) e[kr] = t[kr1];
+      if (bi == kb && kb1 == kb) {  // row K+1 lies in the pivot row's block row: nothing special (row K is fixed below)
+      }
+#pragma unroll
+      for (int q = 0; q < BS; ++q) s[kr1 * BS + q] = e[q];
+      if (bi == kb1) {
+#pragma unroll
+        for (int q = 0; q < BS; q += 2) *reinterpret_cast<double2*>(&ubuf[BS * bj + q]) = double2{e[q], e[q + 1]};
+      }
+      dn = readlane_f64(e[kr1], 9 * kb1);
+      pn = pin_here(fast_rcp(dn));
     }
 #pragma unroll
     for (int r = 0; r < BS; ++r)
+      if (!(more && r == kr1)) {
 #pragma unroll
-      for (int q = 0; q < BS; ++q)
-        if (!(K + 1 < NB && r == kr1 && q == kr1)) s[r * BS + q] = fma(-ur[r], wc[q], s[r * BS + q]);
-    if (bj == kb) {  // pivot column: new (row, K) = (pivot row entry at that row) / pivot, by symmetry
+        for (int q = 0; q < BS; ++q) s[r * BS + q] = fma(-t[r], uc[q], s[r * BS + q]);
+      }
+    if (bj == kb) {  // pivot column
 #pragma unroll
-      for (int r = 0; r < BS; ++r) s[r * BS + kr] = ur[r] * pinv;
+      for (int r = 0; r < BS; ++r) s[r * BS + kr] = t[r];
     }
-    if (bi == kb) {  // pivot row (also fixes (K, K) = -1/pivot)
+    if (bi == kb) {  // pivot row: scaled raw row; (K, K) = -1/pivot
 #pragma unroll
-      for (int q = 0; q < BS; ++q) s[kr * BS + q] = wc[q];
+      for (int q = 0; q < BS; ++q) s[kr * BS + q] = uc[q] * pinv;
+      if (bj == kb) s[kr * BS + kr] = -pinv;
     }
-    SweepStepBlk<NB, K + 1>::run(s, ubuf, wbuf, bi, bj, bad, dn, pn);
+    SweepStepBlk<NB, K + 1>::run(s, ubuf, bi, bj, bad, dn, pn);
   }
 };
 template <int NB>
 struct SweepStepBlk<NB, NB> {
-  static __device__ __forceinline__ void run(double (&)[(NB / 8) * (NB / 8)], double*, double*, int, int, int&,
-                                             double, double) {}
+  static __device__ __forceinline__ void run(double (&)[(NB / 8) * (NB / 8)], double*, int, int, int&, double,
+                                             double) {}
 };
 
 // entry: pivot 0 and its reciprocal, then the pipelined steps
 template <int NB>
 __device__ __forceinline__ void sweep_blk(double (&s)[(NB / 8) * (NB / 8)], double* ubuf, double* wbuf, int bi,
                                           int bj, int& bad) {
+  constexpr int BS = NB / 8;
+  if (bi == 0) {
+#pragma unroll
+    for (int q = 0; q < BS; q += 2) *reinterpret_cast<double2*>(&ubuf[BS * bj + q]) = double2{s[q], s[q + 1]};
+  }
   const double d0 = readlane_f64(s[0], 0);
-  SweepStepBlk<NB, 0>::run(s, ubuf, wbuf, bi, bj, bad, d0, fast_rcp(d0));
+  SweepStepBlk<NB, 0>::run(s, ubuf, bi, bj, bad, d0, fast_rcp(d0));
+  (void)wbuf;
 }
 
 }  // namespace hommx
