@@ -14,8 +14,9 @@
 //      N      = -S^-1                     symmetric Gauss-Jordan sweep, matrix held in VGPRs
 //      V'     = W N                       v_mfma_f64_16x16x4_f64, A operand from LDS, B from VGPRs
 //      S_last += V' W^T                   v_mfma_f64_16x16x4_f64, both operands in VGPRs
-//      W_next = V' E^T                    sparse (neighbour column by a 16-lane rotation, no LDS staging)
-//      S_next = D_{j+1} + E N E^T         E = coupling row j+1 <- row j, bidiagonal (2 nnz/row)
+//      X      = N E^T                     sparse (E = coupling row j+1 <- row j, bidiagonal), VALU
+//      W_next = V' E^T = W X              v_mfma_f64_16x16x4_f64 again: no cross-lane traffic at all
+//      S_next = D_{j+1} + E X             sparse, VALU
 // Sign convention: the sweep produces N = -S^-1; primes mark quantities carrying that sign.
 //
 // Register layouts (l = lane):
@@ -74,7 +75,6 @@ struct alignas(16) Lds {
   double vrbuf[2][NB];   // Vr' = R N
   double e0[NB];         // E[r][r]
   double e1[NB];         // E[r][r-1]
-  double vcol[NB];       // V'[:, n-1]: the wrap-around neighbour column of W_next
   double slbuf[NB * NB]; // S_last accumulators parked between two S_last updates (lane-private slots)
 };
 
@@ -239,8 +239,6 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #endif
   double g00 = 0.0, g01 = 0.0, g11 = 0.0;  // -G partial sums (every lane group holds a copy)
   int bad = 0, badstep = 0;
-  const int kq = (n - 1) >> 2, lq = (n - 1) & 3;  // where column n-1 lives in operand layout
-  const int rotsrc = (l - 16) & 63;
 
   // ---- elimination of node rows 0 .. n-2 ----------------------------------------------------------
   for (int j = 0; j <= n - 2; ++j) {
@@ -367,15 +365,6 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       L.vrbuf[0][c] = vr[0];
       L.vrbuf[1][c] = vr[1];
     }
-    // column n-1 of V' (wrap-around neighbour of column 0) -> vcol
-    if (!lastStep && l4 == lq) {
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-        if (kk == kq) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) L.vcol[16 * t + l15] = vt[kk >> 2][t][kk & 3];
-        }
-    }
     __syncthreads();
 
 #ifndef HOMMX_ABLATE_RL
@@ -413,41 +402,11 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 
 #endif
     if (!lastStep) {
-#ifndef HOMMX_ABLATE_WNEXT
-      // (7) W_next = V' E^T : W_next[i][col] = V'[i][col] e0[col] + V'[i][col-1] e1[col].
-      //     In operand layout column col = 4 kk + (l >> 4): the left neighbour sits 16 lanes down (same kk) or,
-      //     for lanes 0-15, in lanes 48-63 of register kk-1; column -1 wraps to n-1 (vcol).
-      int rot = rotsrc;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        double zprev = L.vcol[16 * t + l15];
-#pragma unroll
-        for (int k4 = 0; k4 < KK; k4 += 4) {
-          // four columns per batch; the shuffle index of the next batch is made to depend (through an empty asm)
-          // on this batch's last result, so that at most 8 ds_bpermute results are live at a time
-          double z[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) z[q] = __shfl(vt[(k4 + q) >> 2][t][(k4 + q) & 3], rot, 64);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int kk = k4 + q;
-            const double x = vt[kk >> 2][t][kk & 3];
-            const double y = (l4 >= 1) ? z[q] : zprev;
-            const double f0 = L.e0[4 * kk + l4], f1 = L.e1[4 * kk + l4];
-            wf[t][kk] = fma(y, f1, x * f0);
-            zprev = z[q];
-          }
-          asm volatile("" : "+v"(rot) : "v"(__double2loint(wf[t][k4 + 3])));
-        }
-      }
-#endif
-#ifndef HOMMX_ABLATE_SNEXT
-      // (8) S_next = D_{j+1} + E N E^T in BLK layout.  With T(r, q) = e0[col q] N[r][col q] + e1[col q] N[r][col q - 1]:
-      //     S_next[r][q] = D[r][q] + e0[row r] T(r, q) + e1[row r] T(r - 1, q);  row -1 / column -1 are cyclic (n - 1).
+      // (7) X = N E^T in BLK layout (overwrites s):  X[r][c] = e0[c] N[r][c] + e1[c] N[r][c-1]   (column -1 is cyclic: n-1)
+      //     Then  W_next = V' E^T = W X  and  S_next = D_{j+1} + E X.
+      double e0q[BS], e1q[BS], e0r[BS], e1r[BS];
       {
-        const int rowm = (bi == 0) ? n - 1 : BS * bi - 1;
         const int colm = (bj == 0) ? n - 1 : BS * bj - 1;
-        double e0q[BS], e1q[BS], e0r[BS], e1r[BS];
 #pragma unroll
         for (int q = 0; q < BS; q += 2) {
           const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[BS * bj + q]);
@@ -457,32 +416,71 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           e0q[q] = a0.x; e0q[q + 1] = a0.y; e1q[q] = a1.x; e1q[q + 1] = a1.y;
           e0r[q] = b0.x; e0r[q + 1] = b0.y; e1r[q] = b1.x; e1r[q + 1] = b1.y;
         }
-        // halo of the block: the row above (with its left neighbour) and the column to the left
-        double hup[BS + 1], hleft[BS];
-        hup[0] = L.mat[midx<NB>(rowm, colm)];
-#pragma unroll
-        for (int q = 0; q < BS; ++q) hup[q + 1] = L.mat[midx<NB>(rowm, BS * bj + q)];
+        double hleft[BS];
 #pragma unroll
         for (int r = 0; r < BS; ++r) hleft[r] = L.mat[midx<NB>(BS * bi + r, colm)];
-        double Tprev[BS];  // T(r - 1, .)
-#pragma unroll
-        for (int q = 0; q < BS; ++q) Tprev[q] = fma(e1q[q], hup[q], e0q[q] * hup[q + 1]);
-        // D_{j+1} through the LDS indexer (all reads of N are done; the buffer is reused)
-        band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
 #pragma unroll
         for (int r = 0; r < BS; ++r) {
-          double Tcur[BS];
+          double prevN = hleft[r];
 #pragma unroll
-          for (int q = 0; q < BS; ++q)
-            Tcur[q] = fma(e1q[q], (q == 0) ? hleft[r] : s[r * BS + q - 1], e0q[q] * s[r * BS + q]);
+          for (int q = 0; q < BS; ++q) {
+            const double cur_n = s[r * BS + q];
+            s[r * BS + q] = fma(e1q[q], prevN, e0q[q] * cur_n);
+            prevN = cur_n;
+          }
+        }
+      }
+      __syncthreads();  // every lane has read its N halo: the buffer can take X
+#pragma unroll
+      for (int r = 0; r < BS; ++r)
+#pragma unroll
+        for (int q = 0; q < BS; q += 2)
+          *reinterpret_cast<double2*>(&L.mat[BLK(r, q)]) = double2{s[r * BS + q], s[r * BS + q + 1]};
+      __syncthreads();
+#ifndef HOMMX_ABLATE_WNEXT
+      // (8) W_next^T = X^T W^T on the matrix cores: the accumulator layout of W_next^T is the operand layout of W_next
+      {
+        d4 wn[NT][NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) wn[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          double af[NT];
+#pragma unroll
+          for (int a = 0; a < NT; ++a) af[a] = L.mat[TILE(a, 4 * kk)];  // A[i][k] = X^T[i][k] = X[k][i]
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              wn[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], wf[b][kk], wn[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) wf[t][kk] = wn[kk >> 2][t][kk & 3];
+      }
+#endif
+#ifndef HOMMX_ABLATE_SNEXT
+      // (8b) S_next[r][c] = D_{j+1}[r][c] + e0[r] X[r][c] + e1[r] X[r-1][c]   (row -1 is cyclic: n-1)
+      {
+        const int rowm = (bi == 0) ? n - 1 : BS * bi - 1;
+        double xup[BS];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) xup[q] = L.mat[midx<NB>(rowm, BS * bj + q)];
+        // D_{j+1} through the LDS indexer (all reads of X are done after the barrier inside)
+        band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
+#pragma unroll
+        for (int r = BS - 1; r >= 0; --r) {
 #pragma unroll
           for (int q = 0; q < BS; q += 2) {
             const double2 dd = *reinterpret_cast<const double2*>(&L.mat[BLK(r, q)]);
-            s[r * BS + q] = fma(e0r[r], Tcur[q], fma(e1r[r], Tprev[q], dd.x));
-            s[r * BS + q + 1] = fma(e0r[r], Tcur[q + 1], fma(e1r[r], Tprev[q + 1], dd.y));
+            const double up0 = (r == 0) ? xup[q] : s[(r > 0 ? r - 1 : 0) * BS + q];
+            const double up1 = (r == 0) ? xup[q + 1] : s[(r > 0 ? r - 1 : 0) * BS + q + 1];
+            s[r * BS + q] = fma(e0r[r], s[r * BS + q], fma(e1r[r], up0, dd.x));
+            s[r * BS + q + 1] = fma(e0r[r], s[r * BS + q + 1], fma(e1r[r], up1, dd.y));
           }
-#pragma unroll
-          for (int q = 0; q < BS; ++q) Tprev[q] = Tcur[q];
         }
       }
 #endif
