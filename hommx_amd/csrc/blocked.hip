@@ -221,55 +221,96 @@ __global__ void k_scatter_plane(Geo G, const double* __restrict__ Kst, double* _
 }
 
 // OUT[k][c] = alpha * sum_{k'} IN[k][k'] E[c][k'],  E = K[(., plane rowPlane), (., plane rowPlane-1)]  (OUT = alpha IN E^T)
-__global__ void k_right_mult_Et(Geo G, const double* __restrict__ Kst, const double* __restrict__ IN,
-                                double* __restrict__ OUT, long long ncells, int nrows, int rowPlane, double alpha) {
+// One thread per output column c and tile of RT rows k: the NE = bs * 3^(d-1) entries of E row c and their
+// column indices are gathered once into registers and reused for every row of the tile.
+template <int NE, int RT>
+__global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __restrict__ Kst,
+                                                       const double* __restrict__ IN, double* __restrict__ OUT,
+                                                       int nrows, int rowPlane, double alpha) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= G.Bp) return;
+  const long long cell = blockIdx.z;
+  const int k0 = blockIdx.y * RT;
   const long long per = (long long)nrows * G.Bp;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncells * per) return;
-  const long long cell = idx / per;
-  const int rem = (int)(idx % per);
-  const int c = rem % G.Bp, k = rem / G.Bp;
-  double acc = 0.0;
+  double e[NE];
+  int kx[NE];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    e[j] = 0.0;
+    kx[j] = 0;
+  }
   if (c < G.b) {
     const int nipc = G.ncode / 3;
     const int q = c / G.bs, al = c % G.bs;
     const int node = q + G.npl * rowPlane;
-    const double* in = IN + cell * per + (long long)k * G.Bp;
-    for (int ipc = 0; ipc < nipc; ++ipc) {
-      const int qn = plane_neighbour(G, q, ipc);
-      for (int be = 0; be < G.bs; ++be) {
-        const double e = Kst[((cell * G.ncode + ipc) * G.bs + al) * G.bs * (long long)G.nn + (long long)be * G.nn + node];
-        acc += in[qn * G.bs + be] * e;
+    const double* kb = Kst + ((cell * G.ncode) * G.bs + al) * G.bs * (long long)G.nn + node;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const int ipc = j / G.bs, be = j % G.bs;
+      if (ipc < nipc) {
+        e[j] = kb[((long long)ipc * G.bs * G.bs + be) * G.nn];
+        kx[j] = plane_neighbour(G, q, ipc) * G.bs + be;
       }
     }
   }
-  OUT[cell * per + (long long)k * G.Bp + c] = alpha * acc;
+  const double* in = IN + cell * per;
+  double* out = OUT + cell * per;
+  const int k1 = min(nrows, k0 + RT);
+  for (int k = k0; k < k1; ++k) {
+    const double* row = in + (long long)k * G.Bp;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) acc = fma(row[kx[j]], e[j], acc);
+    out[(long long)k * G.Bp + c] = alpha * acc;
+  }
 }
 
-// OUT[r][c] = alpha * sum_k E[r][k] X[k][c]   (Bp x Bp)
-__global__ void k_left_mult_E(Geo G, const double* __restrict__ Kst, const double* __restrict__ X,
-                              double* __restrict__ OUT, long long ncells, int rowPlane, double alpha) {
+// OUT[r][c] = alpha * sum_k E[r][k] X[k][c]   (Bp x Bp).  One workgroup per node q (its bs rows r = q bs + al):
+// the bs x NE entries of E and the NE row indices are staged in LDS once; every thread then walks its columns c,
+// loading each X[k][c] once for the bs output rows.
+template <int BSV, int NE>
+__global__ __launch_bounds__(256) void k_left_mult_E(Geo G, const double* __restrict__ Kst,
+                                                     const double* __restrict__ X, double* __restrict__ OUT,
+                                                     int rowPlane, double alpha) {
+  __shared__ double es[BSV][NE];
+  __shared__ int ks[NE];
+  const long long cell = blockIdx.z;
+  const int q = blockIdx.x;  // node in plane; rows q*BSV .. q*BSV+BSV-1 ; q >= npl: padding rows
   const long long per = (long long)G.Bp * G.Bp;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncells * per) return;
-  const long long cell = idx / per;
-  const int rem = (int)(idx % per);
-  const int c = rem % G.Bp, r = rem / G.Bp;
-  double acc = 0.0;
-  if (r < G.b) {
-    const int nipc = G.ncode / 3;
-    const int q = r / G.bs, al = r % G.bs;
-    const int node = q + G.npl * rowPlane;
-    const double* x = X + cell * per + c;
-    for (int ipc = 0; ipc < nipc; ++ipc) {
-      const int qn = plane_neighbour(G, q, ipc);
-      for (int be = 0; be < G.bs; ++be) {
-        const double e = Kst[((cell * G.ncode + ipc) * G.bs + al) * G.bs * (long long)G.nn + (long long)be * G.nn + node];
-        acc += e * x[(long long)(qn * G.bs + be) * G.Bp];
-      }
+  double* out = OUT + cell * per;
+  if (q * BSV >= G.b) {  // padding rows: zero
+    for (int al = 0; al < BSV; ++al) {
+      const int r = q * BSV + al;
+      if (r < G.Bp)
+        for (int c = threadIdx.x; c < G.Bp; c += 256) out[(long long)r * G.Bp + c] = 0.0;
     }
+    return;
   }
-  OUT[cell * per + (long long)r * G.Bp + c] = alpha * acc;
+  const int nipc = G.ncode / 3;
+  if (threadIdx.x < NE) {
+    const int j = threadIdx.x, ipc = j / BSV, be = j % BSV;
+    const int node = q + G.npl * rowPlane;
+    ks[j] = plane_neighbour(G, q, ipc < nipc ? ipc : 0) * BSV + be;
+    for (int al = 0; al < BSV; ++al)
+      es[al][j] = (ipc < nipc)
+                      ? Kst[((cell * G.ncode + ipc) * BSV + al) * BSV * (long long)G.nn + (long long)be * G.nn + node]
+                      : 0.0;
+  }
+  __syncthreads();
+  const double* x = X + cell * per;
+  for (int c = threadIdx.x; c < G.Bp; c += 256) {
+    double acc[BSV];
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) acc[al] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const double xv = x[(long long)ks[j] * G.Bp + c];
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) acc[al] = fma(es[al][j], xv, acc[al]);
+    }
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) out[(long long)(q * BSV + al) * G.Bp + c] = alpha * acc[al];
+  }
 }
 
 // R[m][c] (+)= B[m][(c in plane)]  (16 x Bp load rows)
@@ -597,6 +638,31 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
     hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
 }
 
+void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha) {
+  const Geo& G = c.ws->G;
+  constexpr int RT = 32;
+  dim3 grid((G.Bp + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
+  const int ne = G.bs * (G.ncode / 3);
+#define HOMMX_RM(NE) hipLaunchKernelGGL((k_right_mult_Et<NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha)
+  if (ne == 3) HOMMX_RM(3);
+  else if (ne == 6) HOMMX_RM(6);
+  else if (ne == 9) HOMMX_RM(9);
+  else HOMMX_RM(27);
+#undef HOMMX_RM
+}
+
+void left_mult_E(const Ctx& c, const double* X, double* OUT, int rowPlane, double alpha) {
+  const Geo& G = c.ws->G;
+  dim3 grid((G.Bp + G.bs - 1) / G.bs, 1, (unsigned)c.nc), block(256);
+  const int ne = G.bs * (G.ncode / 3);
+#define HOMMX_LM(BSV, NE) hipLaunchKernelGGL((k_left_mult_E<BSV, NE>), grid, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha)
+  if (ne == 3) HOMMX_LM(1, 3);
+  else if (ne == 6) HOMMX_LM(2, 6);
+  else if (ne == 9) HOMMX_LM(1, 9);
+  else HOMMX_LM(3, 27);
+#undef HOMMX_LM
+}
+
 // in-place inverse of the SPD diagonal block [off, off+size) of every cell's matrix S (ld = Bp), recursive
 // Schur-complement form; `tmp` points at free scratch (consumed stack-like by the nesting levels)
 void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
@@ -670,11 +736,11 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
       gemm(c, false, true, 16, 16, Bp, 1.0, ws->Vr, Bp, 16ll * Bp, ws->R, Bp, 16ll * Bp, 1.0, ws->Gm, 16, 256);   // G += Vr R^T
       gemm(c, false, true, 16, Bp, Bp, -1.0, ws->Vr, Bp, 16ll * Bp, ws->W, Bp, mat, 1.0, ws->Rl, Bp, 16ll * Bp);  // R_last -= Vr W^T
       if (!last) {
-        hipLaunchKernelGGL(k_right_mult_Et, dim3(nblk(nc * mat)), dim3(256), 0, st, G, ws->Kst, ws->S, ws->X, nc, Bp, j + 1, 1.0);   // X = Sinv E^T
-        hipLaunchKernelGGL(k_left_mult_E, dim3(nblk(nc * mat)), dim3(256), 0, st, G, ws->Kst, ws->X, ws->S, nc, j + 1, -1.0);        // S = -E X
+        right_mult_Et(c, ws->S, ws->X, Bp, j + 1, 1.0);   // X = Sinv E^T
+        left_mult_E(c, ws->X, ws->S, j + 1, -1.0);        // S = -E X
         hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->S, nc, j + 1, 0, 1);                 // S += D_{j+1}
-        hipLaunchKernelGGL(k_right_mult_Et, dim3(nblk(nc * mat)), dim3(256), 0, st, G, ws->Kst, ws->V, ws->W, nc, Bp, j + 1, -1.0);  // W = -V E^T
-        hipLaunchKernelGGL(k_right_mult_Et, dim3(nblk(nc * 16ll * Bp)), dim3(256), 0, st, G, ws->Kst, ws->Vr, ws->R, nc, 16, j + 1, -1.0);  // R = -Vr E^T
+        right_mult_Et(c, ws->V, ws->W, Bp, j + 1, -1.0);  // W = -V E^T
+        right_mult_Et(c, ws->Vr, ws->R, 16, j + 1, -1.0);  // R = -Vr E^T
         hipLaunchKernelGGL(k_add_P, dim3(nblk(nc * 16ll * Bp)), dim3(256), 0, st, G, ws->Brhs, ws->R, nc, j + 1, 0);                 // R += P_{j+1}
       }
     }
