@@ -319,12 +319,13 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 
 #ifndef HOMMX_ABLATE_GEMM2
     // (4) S_last += V' W^T.  The accumulators (C layout) live in lane-private LDS slots between two updates.
+    //     S_last is symmetric: only the tiles on and below the diagonal are kept (3 of 4 for NB = 32).
     {
       d4 sl[NT][NT];
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+        for (int b = 0; b <= a; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sl[a][b][r] = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
 #pragma unroll
@@ -332,12 +333,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
-          for (int b = 0; b < NT; ++b)
+          for (int b = 0; b <= a; ++b)
             sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+        for (int b = 0; b <= a; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) L.slbuf[((a * NT + b) * 4 + r) * 64 + l] = sl[a][b][r];
     }
@@ -498,9 +499,13 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+    for (int b = 0; b <= a; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) L.mat[TILE(b, 16 * a + 4 * r)] = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
+      for (int r = 0; r < 4; ++r) {
+        const double v = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
+        L.mat[TILE(b, 16 * a + 4 * r)] = v;                                          // (16a + l4 + 4r, 16b + l15)
+        if (b < a) L.mat[midx<NB>(16 * b + l15, 16 * a + 4 * r + l4)] = v;           // mirror image
+      }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < BS; ++r)
