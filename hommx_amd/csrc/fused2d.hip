@@ -75,6 +75,7 @@ struct alignas(16) Lds {
   double vrbuf[2][NB];   // Vr' = R N
   double e0[NB];         // E[r][r]
   double e1[NB];         // E[r][r-1]
+  double vcol[NB];       // V'[:, n-1]: the wrap-around neighbour column of W_next
   double slbuf[NB * NB]; // S_last accumulators parked between two S_last updates (lane-private slots)
 };
 
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #endif
   double g00 = 0.0, g01 = 0.0, g11 = 0.0;  // -G partial sums (every lane group holds a copy)
   int bad = 0, badstep = 0;
+  const int kq = (n - 1) >> 2, lq = (n - 1) & 3;  // where column n-1 lives in operand layout
+  const int rotsrc = (l - 16) & 63;
 
   // ---- elimination of node rows 0 .. n-2 ----------------------------------------------------------
   for (int j = 0; j <= n - 2; ++j) {
@@ -366,6 +369,15 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       L.vrbuf[0][c] = vr[0];
       L.vrbuf[1][c] = vr[1];
     }
+    // column n-1 of V' (wrap-around neighbour of column 0) -> vcol
+    if (!lastStep && l4 == lq) {
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        if (kk == kq) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) L.vcol[16 * t + l15] = vt[kk >> 2][t][kk & 3];
+        }
+    }
     __syncthreads();
 
 #ifndef HOMMX_ABLATE_RL
@@ -403,11 +415,49 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 
 #endif
     if (!lastStep) {
-      // (7) X = N E^T in BLK layout (overwrites s):  X[r][c] = e0[c] N[r][c] + e1[c] N[r][c-1]   (column -1 is cyclic: n-1)
-      //     Then  W_next = V' E^T = W X  and  S_next = D_{j+1} + E X.
-      double e0q[BS], e1q[BS], e0r[BS], e1r[BS];
+#ifndef HOMMX_ABLATE_WNEXT
+      // (7) W_next = V' E^T (sparse):  W_next[i][col] = V'[i][col] e0[col] + V'[i][col-1] e1[col].
+      //     In operand layout col = 4 kk + (l >> 4): the left neighbour of a lane's column sits 16 lanes down; for lanes
+      //     0-15 it is lanes 48-63 of register kk-1, and column -1 wraps to n-1 (vcol).  The select is done on the
+      //     SOURCE side (lanes 48-63 offer register kk-1), then one 16-lane rotation brings every lane its neighbour.
       {
+        double f0[KK], f1[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          f0[kk] = L.e0[4 * kk + l4];
+          f1[kk] = L.e1[4 * kk + l4];
+        }
+        int rot = rotsrc;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const double wrapv = L.vcol[16 * t + l15];
+#pragma unroll
+          for (int k4 = 0; k4 < KK; k4 += 4) {
+            double z[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int kk = k4 + q;
+              const double xk = vt[kk >> 2][t][kk & 3];
+              const double xm = (kk == 0) ? wrapv : vt[(kk > 0 ? kk - 1 : 0) >> 2][t][(kk > 0 ? kk - 1 : 0) & 3];
+              z[q] = __shfl((l4 == 3) ? xm : xk, rot, 64);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int kk = k4 + q;
+              wf[t][kk] = fma(z[q], f1[kk], vt[kk >> 2][t][kk & 3] * f0[kk]);
+            }
+            asm volatile("" : "+v"(rot) : "v"(__double2loint(wf[t][k4 + 3])));  // bound the shuffles in flight
+          }
+        }
+      }
+#endif
+#ifndef HOMMX_ABLATE_SNEXT
+      // (8) S_next = D_{j+1} + E N E^T in BLK layout.  With X(r, q) = e0[col q] N[r][col q] + e1[col q] N[r][col q - 1]:
+      //     S_next[r][q] = D[r][q] + e0[row r] X(r, q) + e1[row r] X(r - 1, q);  row -1 / column -1 are cyclic (n - 1).
+      {
+        const int rowm = (bi == 0) ? n - 1 : BS * bi - 1;
         const int colm = (bj == 0) ? n - 1 : BS * bj - 1;
+        double e0q[BS], e1q[BS], e0r[BS], e1r[BS];
 #pragma unroll
         for (int q = 0; q < BS; q += 2) {
           const double2 a0 = *reinterpret_cast<const double2*>(&L.e0[BS * bj + q]);
@@ -417,9 +467,17 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           e0q[q] = a0.x; e0q[q + 1] = a0.y; e1q[q] = a1.x; e1q[q + 1] = a1.y;
           e0r[q] = b0.x; e0r[q + 1] = b0.y; e1r[q] = b1.x; e1r[q + 1] = b1.y;
         }
-        double hleft[BS];
+        // halo of the block in N: the row above (with its left neighbour) and the column to the left
+        double hup[BS + 1], hleft[BS];
+        hup[0] = L.mat[midx<NB>(rowm, colm)];
+#pragma unroll
+        for (int q = 0; q < BS; ++q) hup[q + 1] = L.mat[midx<NB>(rowm, BS * bj + q)];
 #pragma unroll
         for (int r = 0; r < BS; ++r) hleft[r] = L.mat[midx<NB>(BS * bi + r, colm)];
+        double xup[BS];  // X(r0 - 1, .)
+#pragma unroll
+        for (int q = 0; q < BS; ++q) xup[q] = fma(e1q[q], hup[q], e0q[q] * hup[q + 1]);
+        // X in place
 #pragma unroll
         for (int r = 0; r < BS; ++r) {
           double prevN = hleft[r];
@@ -430,47 +488,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
             prevN = cur_n;
           }
         }
-      }
-      __syncthreads();  // every lane has read its N halo: the buffer can take X
-#pragma unroll
-      for (int r = 0; r < BS; ++r)
-#pragma unroll
-        for (int q = 0; q < BS; q += 2)
-          *reinterpret_cast<double2*>(&L.mat[BLK(r, q)]) = double2{s[r * BS + q], s[r * BS + q + 1]};
-      __syncthreads();
-#ifndef HOMMX_ABLATE_WNEXT
-      // (8) W_next^T = X^T W^T on the matrix cores: the accumulator layout of W_next^T is the operand layout of W_next
-      {
-        d4 wn[NT][NT];
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int b = 0; b < NT; ++b) wn[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          double af[NT];
-#pragma unroll
-          for (int a = 0; a < NT; ++a) af[a] = L.mat[TILE(a, 4 * kk)];  // A[i][k] = X^T[i][k] = X[k][i]
-#pragma unroll
-          for (int a = 0; a < NT; ++a)
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-              wn[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], wf[b][kk], wn[a][b], 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int kk = 0; kk < KK; ++kk) wf[t][kk] = wn[kk >> 2][t][kk & 3];
-      }
-#endif
-#ifndef HOMMX_ABLATE_SNEXT
-      // (8b) S_next[r][c] = D_{j+1}[r][c] + e0[r] X[r][c] + e1[r] X[r-1][c]   (row -1 is cyclic: n-1)
-      {
-        const int rowm = (bi == 0) ? n - 1 : BS * bi - 1;
-        double xup[BS];
-#pragma unroll
-        for (int q = 0; q < BS; ++q) xup[q] = L.mat[midx<NB>(rowm, BS * bj + q)];
-        // D_{j+1} through the LDS indexer (all reads of X are done after the barrier inside)
+        // D_{j+1} through the LDS indexer (every lane has read its N halo after the barrier inside)
         band_D_to_mat(st_diag(nxt, cur), st_E(nxt, cur));
 #pragma unroll
         for (int r = BS - 1; r >= 0; --r) {
