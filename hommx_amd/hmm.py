@@ -193,19 +193,59 @@ class BaseHMM(ABC):
         return v
 
     def _element_means(self, cells: np.ndarray) -> tuple[np.ndarray, str]:
-        d, n = self._tdim, self._n_micro
+        d = self._tdim
         bary, w = micro_quadrature(d, self._quadrature_degree)
         Xe = self._cell_mesh.cell_vertices()  # [n_el, d+1, d]
         yq = np.einsum("qa,eak->eqk", bary, Xe)
         n_el, nq = yq.shape[:2]
         yflat = yq.reshape(-1, d).T
         c = self._msh.cell_midpoints()[cells]
-        first = self._sample_one(c[0], yflat)
-        out = np.empty((len(cells),) + (n_el,) + first.shape[1:])
-        for k in range(len(cells)):
-            v = first if k == 0 else self._sample_one(c[k], yflat)
-            out[k] = np.tensordot(w, v.reshape((n_el, nq) + v.shape[1:]), axes=([0], [1]))
+        out = self._sample_batched(c, yflat, n_el, nq, w)
+        if out is None:  # the callable is not broadcastable over cells: one call per macro cell (as the reference)
+            first = self._sample_one(c[0], yflat)
+            out = np.empty((len(cells),) + (n_el,) + first.shape[1:])
+            for k in range(len(cells)):
+                v = first if k == 0 else self._sample_one(c[k], yflat)
+                out[k] = np.tensordot(w, v.reshape((n_el, nq) + v.shape[1:]), axes=([0], [1]))
         return self._pack_coefficient(out)
+
+    def _sample_batched(self, c: np.ndarray, yflat: np.ndarray, n_el: int, nq: int, w: np.ndarray):
+        """Try ONE broadcast call A(x[3, N_c, 1], y[d, 1, npts]) -> [N_c, npts(, ...)] per chunk of cells; accept it only
+        if it reproduces the per-cell call on the first and last cell.  Returns None when the callable cannot broadcast."""
+        nc, npts = c.shape[0], yflat.shape[1]
+        if nc < 4:
+            return None
+        try:
+            ref0 = self._sample_one(c[0], yflat)
+            ref1 = self._sample_one(c[-1], yflat)
+            chunk = max(1, int(2.0e7 // max(1, npts)))
+            parts = []
+            for a in range(0, nc, chunk):
+                xb = c[a : a + chunk].T[:, :, None]
+                v = self._coeff(xb, yflat[:, None, :])
+                if isinstance(v, Lame):
+                    lam = np.broadcast_to(np.asarray(v.lam, float), (xb.shape[1], npts))
+                    mu = np.broadcast_to(np.asarray(v.mu, float), (xb.shape[1], npts))
+                    v = np.stack([lam, mu], axis=-1)
+                else:
+                    v = np.asarray(v, dtype=float)
+                    if v.ndim < 2 or v.shape[:2] != (xb.shape[1], npts):
+                        if v.ndim >= 2 and v.shape[:2] == (1, npts) or v.ndim == 0:
+                            v = np.broadcast_to(v, (xb.shape[1], npts) + v.shape[2:]) if v.ndim else np.full((xb.shape[1], npts), float(v))
+                        else:
+                            return None
+                if nq == 1:  # centroid rule: the mean IS the sample (no copy)
+                    parts.append(v.reshape((v.shape[0], n_el) + v.shape[2:]))
+                else:
+                    parts.append(np.tensordot(v.reshape((v.shape[0], n_el, nq) + v.shape[2:]), w, axes=([2], [0])))
+            out = parts[0] if len(parts) == 1 else np.concatenate(parts, axis=0)
+            chk0 = np.tensordot(w, ref0.reshape((n_el, nq) + ref0.shape[1:]), axes=([0], [1]))
+            chk1 = np.tensordot(w, ref1.reshape((n_el, nq) + ref1.shape[1:]), axes=([0], [1]))
+            if out[0].shape != chk0.shape or not (np.allclose(out[0], chk0, rtol=1e-14, atol=0) and np.allclose(out[-1], chk1, rtol=1e-14, atol=0)):
+                return None
+            return out
+        except Exception:
+            return None
 
     def _pack_coefficient(self, means: np.ndarray) -> tuple[np.ndarray, str]:
         """Element means -> the layout of include/hommx_hip.h for the plan kind."""
