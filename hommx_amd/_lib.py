@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = (
     "hommx_plan_kernel_name",
     "hommx_solve_batch",
     "hommx_solve_batch_device",
+    "hommx_solve_batch_correctors",
     "hommx_calibrate_fp64_mfma",
     "hommx_last_error",
 )
@@ -84,6 +85,8 @@ def load():
     lib.hommx_solve_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.hommx_solve_batch_device.restype = C.c_int
     lib.hommx_solve_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.hommx_solve_batch_correctors.restype = C.c_int
+    lib.hommx_solve_batch_correctors.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.hommx_calibrate_fp64_mfma.restype = C.c_int
     lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
     lib.hommx_last_error.restype = C.c_char_p

@@ -53,8 +53,12 @@ class MicroCellPlan:
             pass
 
     # -- host arrays -----------------------------------------------------------------------------
-    def solve(self, coef: np.ndarray, M: np.ndarray | None = None, return_info: bool = False):
-        """coef[N_c, n_el(, n_comp)] float64, M[N_c, d, d] or None -> A_eff[N_c, t, t] (and info[N_c])."""
+    def solve(self, coef: np.ndarray, M: np.ndarray | None = None, return_info: bool = False,
+              return_correctors: bool = False):
+        """coef[N_c, n_el(, n_comp)] float64, M[N_c, d, d] or None -> A_eff[N_c, t, t] (and info[N_c]).
+
+        With ``return_correctors`` the result is (A_eff, correctors[N_c, t, n^d * bs][, info]): the periodic cell solutions
+        of the canonical loads (mean-free), dof = node * bs + component."""
         coef = np.ascontiguousarray(coef, dtype=np.float64)
         nc = coef.shape[0]
         if coef.size != nc * self.n_el * self.n_comp:
@@ -70,6 +74,17 @@ class MicroCellPlan:
             Mp = M.ctypes.data
         out = np.empty((nc, self.t, self.t), dtype=np.float64)
         info = np.zeros(nc, dtype=np.int32)
+        if return_correctors:
+            bs = 1 if self.kind.startswith("poisson") else self.dim
+            corr = np.empty((nc, self.t, self.n_micro**self.dim * bs), dtype=np.float64)
+            if nc:
+                _lib.check(
+                    self._lib.hommx_solve_batch_correctors(
+                        self._h, nc, coef.ctypes.data, Mp, out.ctypes.data, corr.ctypes.data, info.ctypes.data
+                    ),
+                    "hommx_solve_batch_correctors",
+                )
+            return (out, corr, info) if return_info else (out, corr)
         if nc:
             _lib.check(
                 self._lib.hommx_solve_batch(self._h, nc, coef.ctypes.data, Mp, out.ctypes.data, info.ctypes.data),

@@ -169,6 +169,63 @@ int hommx_solve_batch(hommx_plan* p, int64_t n_cells, const double* coef, const 
   return HOMMX_OK;
 }
 
+int hommx_solve_batch_correctors(hommx_plan* p, int64_t n_cells, const double* coef, const double* M, double* A_eff,
+                                 double* correctors, int32_t* info) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (!coef || !A_eff || !correctors) return fail(HOMMX_EINVAL, "null coef / A_eff / correctors");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  if (!p->ws) {
+    int rc = hommx::blocked_workspace_create(&p->ws, p->desc.dim, p->desc.n_micro, p->desc.kind);
+    if (rc != 0) return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+  }
+  const int d = p->desc.dim, t = p->t;
+  const int bs = (p->desc.kind >= HOMMX_KIND_ELASTICITY_ISO) ? d : 1;
+  long long nn = 1;
+  for (int k = 0; k < d; ++k) nn *= p->desc.n_micro;
+  double *d_coef = nullptr, *d_M = nullptr, *d_out = nullptr, *d_corr = nullptr;
+  int32_t* d_info = nullptr;
+  auto cleanup = [&]() {
+    if (d_coef) hipFree(d_coef);
+    if (d_M) hipFree(d_M);
+    if (d_out) hipFree(d_out);
+    if (d_corr) hipFree(d_corr);
+    if (d_info) hipFree(d_info);
+  };
+#define HIP_TRY_C(expr)                                                                             \
+  do {                                                                                              \
+    hipError_t e__ = (expr);                                                                        \
+    if (e__ != hipSuccess) {                                                                        \
+      cleanup();                                                                                    \
+      return fail(e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP, "%s failed: %s", #expr,   \
+                  hipGetErrorString(e__));                                                          \
+    }                                                                                               \
+  } while (0)
+  const size_t ncoef = sizeof(double) * n_cells * p->n_el * p->n_comp, ncorr = sizeof(double) * n_cells * t * nn * bs;
+  HIP_TRY_C(hipMalloc(&d_coef, ncoef));
+  HIP_TRY_C(hipMalloc(&d_out, sizeof(double) * n_cells * t * t));
+  HIP_TRY_C(hipMalloc(&d_corr, ncorr));
+  HIP_TRY_C(hipMalloc(&d_info, sizeof(int32_t) * n_cells));
+  HIP_TRY_C(hipMemcpy(d_coef, coef, ncoef, hipMemcpyHostToDevice));
+  if (M) {
+    HIP_TRY_C(hipMalloc(&d_M, sizeof(double) * n_cells * d * d));
+    HIP_TRY_C(hipMemcpy(d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
+  }
+  int rc = hommx::blocked_solve(p->ws, n_cells, d_coef, d_M, d_out, d_info, nullptr, d_corr);
+  if (rc != 0) {
+    cleanup();
+    return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+  }
+  HIP_TRY_C(hipDeviceSynchronize());
+  HIP_TRY_C(hipMemcpy(A_eff, d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
+  HIP_TRY_C(hipMemcpy(correctors, d_corr, ncorr, hipMemcpyDeviceToHost));
+  if (info) HIP_TRY_C(hipMemcpy(info, d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
+#undef HIP_TRY_C
+  cleanup();
+  return HOMMX_OK;
+}
+
 int hommx_calibrate_fp64_mfma(int device, double* flops_per_s) {
   if (!flops_per_s) return fail(HOMMX_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(device));

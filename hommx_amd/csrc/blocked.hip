@@ -220,13 +220,15 @@ __global__ void k_scatter_plane(Geo G, const double* __restrict__ Kst, double* _
   }
 }
 
-// OUT[k][c] = alpha * sum_{k'} IN[k][k'] E[c][k'],  E = K[(., plane rowPlane), (., plane rowPlane-1)]  (OUT = alpha IN E^T)
+// OUT[k][c] (+)= alpha * sum_{k'} IN[k][k'] E[c][k'],  E = K[(., plane rowPlane), (., plane rowPlane + o)]  (OUT = alpha IN E^T);
+// o = -1 (codeOff = 0, the elimination) or +1 (codeOff = 2 * 3^(d-1), the back substitution).
 // One thread per output column c and tile of RT rows k: the NE = bs * 3^(d-1) entries of E row c and their
 // column indices are gathered once into registers and reused for every row of the tile.
 template <int NE, int RT>
 __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __restrict__ Kst,
                                                        const double* __restrict__ IN, double* __restrict__ OUT,
-                                                       int nrows, int rowPlane, double alpha) {
+                                                       int nrows, int rowPlane, double alpha, int codeOff,
+                                                       int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= G.Bp) return;
   const long long cell = blockIdx.z;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __re
     for (int j = 0; j < NE; ++j) {
       const int ipc = j / G.bs, be = j % G.bs;
       if (ipc < nipc) {
-        e[j] = kb[((long long)ipc * G.bs * G.bs + be) * G.nn];
+        e[j] = kb[((long long)(ipc + codeOff) * G.bs * G.bs + be) * G.nn];
         kx[j] = plane_neighbour(G, q, ipc) * G.bs + be;
       }
     }
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __re
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < NE; ++j) acc = fma(row[kx[j]], e[j], acc);
-    out[(long long)k * G.Bp + c] = alpha * acc;
+    double* o = out + (long long)k * G.Bp + c;
+    *o = accumulate ? *o + alpha * acc : alpha * acc;
   }
 }
 
@@ -353,6 +356,36 @@ __global__ void k_finalize(Geo G, const double* __restrict__ C0, const double* _
   const long long cell = idx / tt;
   const int m = (int)(idx % tt) / G.t, q = (int)(idx % tt) % G.t;
   out[idx] = C0[idx] - Gm[cell * 256 + m * 16 + q];
+}
+
+// corr[cell][m][plane * b + r] = X[cell][m][r]   (t load cases, periodic dof numbering (node, component))
+__global__ void k_store_corr(Geo G, const double* __restrict__ X, double* __restrict__ corr, long long ncells, int plane) {
+  const long long per = (long long)G.t * G.b;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int r = rem % G.b, m = rem / G.b;
+  corr[(cell * G.t + m) * (long long)G.nn * G.bs + (long long)plane * G.b + r] = X[cell * 16ll * G.Bp + (long long)m * G.Bp + r];
+}
+
+// remove the mean of every component (the reference projects the constants out: cell_problem.py:349-361, 382)
+__global__ __launch_bounds__(256) void k_center_corr(Geo G, double* __restrict__ corr) {
+  __shared__ double red[256];
+  double* x = corr + (long long)blockIdx.x * G.nn * G.bs;  // one (cell, load case) per block
+  for (int al = 0; al < G.bs; ++al) {
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < G.nn; p += 256) acc += x[(long long)p * G.bs + al];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    const double mean = red[0] / G.nn;
+    __syncthreads();
+    for (int p = threadIdx.x; p < G.nn; p += 256) x[(long long)p * G.bs + al] -= mean;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -497,6 +530,9 @@ struct BlockedWorkspace {
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
   double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
   double *R = nullptr, *Rl = nullptr, *Vr = nullptr, *Gm = nullptr;
+  // corrector mode: per eliminated plane the inverse Schur block, the arrow block and the load rows are kept
+  long long hchunk = 0;
+  double *hS = nullptr, *hW = nullptr, *hR = nullptr, *Xa = nullptr, *Xb = nullptr, *Y = nullptr;
 };
 
 static void fill_tables(Geo& G) {
@@ -565,14 +601,27 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   return 0;
 }
 
-static void ws_free(BlockedWorkspace* ws) {
-  double** ptrs[] = {&ws->Kst, &ws->Brhs, &ws->C0, &ws->S, &ws->W, &ws->Sl, &ws->V, &ws->X, &ws->T,
-                     &ws->R,   &ws->Rl,   &ws->Vr, &ws->Gm};
+static void ws_free_main(BlockedWorkspace* ws) {
+  double** ptrs[] = {&ws->Kst, &ws->Brhs, &ws->C0, &ws->S, &ws->W, &ws->Sl, &ws->V, &ws->X, &ws->T, &ws->R, &ws->Rl, &ws->Vr, &ws->Gm};
   for (auto p : ptrs) {
     if (*p) hipFree(*p);
     *p = nullptr;
   }
   ws->chunk = 0;
+}
+
+static void ws_free_hist(BlockedWorkspace* ws) {
+  double** ptrs[] = {&ws->hS, &ws->hW, &ws->hR, &ws->Xa, &ws->Xb, &ws->Y};
+  for (auto p : ptrs) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  ws->hchunk = 0;
+}
+
+static void ws_free(BlockedWorkspace* ws) {
+  ws_free_main(ws);
+  ws_free_hist(ws);
 }
 
 void blocked_workspace_destroy(BlockedWorkspace* ws) {
@@ -586,16 +635,34 @@ static long long per_cell_bytes(const Geo& G) {
   return 8ll * ((long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36 + 6 * mat + 3 * 16ll * G.Bp + 256);
 }
 
-static int ws_reserve(BlockedWorkspace* ws, long long ncells) {
+static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
   const Geo& G = ws->G;
   double budget_gb = 16.0;
   if (const char* e = getenv("HOMMX_BLOCKED_MEM_GB")) budget_gb = atof(e);
+  const long long hist_bytes = 8ll * (G.n - 1) * (2ll * G.Bp * G.Bp + 16ll * G.Bp) + 8ll * 3 * 16 * G.Bp;
+  if (correctors) {
+    long long hc = (long long)(budget_gb * 1e9) / (per_cell_bytes(G) + hist_bytes);
+    if (hc < 1) hc = 1;
+    if (hc > 8192) hc = 8192;
+    if (hc > ncells) hc = ncells;
+    if (hc > ws->hchunk) {
+      ws_free_hist(ws);
+      const long long mat = (long long)G.Bp * G.Bp;
+      BTRY(hipMalloc(&ws->hS, 8ll * hc * (G.n - 1) * mat));
+      BTRY(hipMalloc(&ws->hW, 8ll * hc * (G.n - 1) * mat));
+      BTRY(hipMalloc(&ws->hR, 8ll * hc * (G.n - 1) * 16 * G.Bp));
+      BTRY(hipMalloc(&ws->Xa, 8ll * hc * 16 * G.Bp));
+      BTRY(hipMalloc(&ws->Xb, 8ll * hc * 16 * G.Bp));
+      BTRY(hipMalloc(&ws->Y, 8ll * hc * 16 * G.Bp));
+      ws->hchunk = hc;
+    }
+  }
   long long chunk = (long long)(budget_gb * 1e9) / per_cell_bytes(G);
   if (chunk < 1) chunk = 1;
   if (chunk > 8192) chunk = 8192;
   if (chunk > ncells) chunk = ncells;
   if (chunk <= ws->chunk) return 0;
-  ws_free(ws);
+  ws_free_main(ws);
   const long long mat = (long long)G.Bp * G.Bp;
   BTRY(hipMalloc(&ws->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
   BTRY(hipMalloc(&ws->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
@@ -638,12 +705,14 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
     hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
 }
 
-void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha) {
+void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha,
+                   int olast = -1, int accumulate = 0) {
   const Geo& G = c.ws->G;
   constexpr int RT = 32;
   dim3 grid((G.Bp + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
-#define HOMMX_RM(NE) hipLaunchKernelGGL((k_right_mult_Et<NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha)
+  const int codeOff = (olast + 1) * (G.ncode / 3);
+#define HOMMX_RM(NE) hipLaunchKernelGGL((k_right_mult_Et<NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate)
   if (ne == 3) HOMMX_RM(3);
   else if (ne == 6) HOMMX_RM(6);
   else if (ne == 9) HOMMX_RM(9);
@@ -696,14 +765,15 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
 }  // namespace
 
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out,
-                  int32_t* d_info, hipStream_t st) {
-  if (int rc = ws_reserve(ws, ncells)) return rc;
+                  int32_t* d_info, hipStream_t st, double* d_corr) {
+  if (int rc = ws_reserve(ws, ncells, d_corr != nullptr)) return rc;
   const Geo& G = ws->G;
   const int n = G.n, Bp = G.Bp;
   const long long mat = (long long)Bp * Bp;
   if (d_info) BTRY(hipMemsetAsync(d_info, 0, sizeof(int32_t) * ncells, st));
-  for (long long c0 = 0; c0 < ncells; c0 += ws->chunk) {
-    const long long nc = std::min(ws->chunk, ncells - c0);
+  const long long step_cells = d_corr ? std::min(ws->chunk, ws->hchunk) : ws->chunk;
+  for (long long c0 = 0; c0 < ncells; c0 += step_cells) {
+    const long long nc = std::min(step_cells, ncells - c0);
     Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
     const double* coef = d_coef + c0 * G.n_el * G.ncomp;
     const double* Mm = d_M ? d_M + c0 * G.dim * G.dim : nullptr;
@@ -730,6 +800,11 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
       if (last)  // the last plane couples to plane n-2 through E as well as through the arrow
         hipLaunchKernelGGL(k_scatter_plane, dim3(nblk(scat)), dim3(256), 0, st, G, ws->Kst, ws->W, nc, n - 1, -1, 0);
       invert(c, ws->S, 0, Bp, ws->T);                                                                   // S <- S^-1
+      if (d_corr) {  // keep what the back substitution needs: S_j^-1, W_j (incl. E on the last step), R_j
+        BTRY(hipMemcpyAsync(ws->hS + (long long)j * nc * mat, ws->S, 8ll * nc * mat, hipMemcpyDeviceToDevice, st));
+        BTRY(hipMemcpyAsync(ws->hW + (long long)j * nc * mat, ws->W, 8ll * nc * mat, hipMemcpyDeviceToDevice, st));
+        BTRY(hipMemcpyAsync(ws->hR + (long long)j * nc * 16 * Bp, ws->R, 8ll * nc * 16 * Bp, hipMemcpyDeviceToDevice, st));
+      }
       gemm(c, false, false, Bp, Bp, Bp, 1.0, ws->W, Bp, mat, ws->S, Bp, mat, 0.0, ws->V, Bp, mat);      // V = W Sinv
       gemm(c, false, true, Bp, Bp, Bp, -1.0, ws->V, Bp, mat, ws->W, Bp, mat, 1.0, ws->Sl, Bp, mat);     // S_last -= V W^T
       gemm(c, false, false, 16, Bp, Bp, 1.0, ws->R, Bp, 16ll * Bp, ws->S, Bp, mat, 0.0, ws->Vr, Bp, 16ll * Bp);   // Vr = R Sinv
@@ -750,6 +825,23 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     invert(c, ws->Sl, 0, Bp, ws->T);
     gemm(c, false, false, 16, Bp, Bp, 1.0, ws->Rl, Bp, 16ll * Bp, ws->Sl, Bp, mat, 0.0, ws->Vr, Bp, 16ll * Bp);
     gemm(c, false, true, 16, 16, Bp, 1.0, ws->Vr, Bp, 16ll * Bp, ws->Rl, Bp, 16ll * Bp, 1.0, ws->Gm, 16, 256);
+    // ---- correctors: back substitution  chi_j = S_j^-1 (r_j - E_j^T chi_{j+1} - W_j^T chi_last), rows = load cases
+    if (d_corr) {
+      double* corr = d_corr + c0 * (long long)G.t * G.nn * G.bs;
+      const long long sx = 16ll * Bp;
+      hipLaunchKernelGGL(k_store_corr, dim3(nblk(nc * (long long)G.t * G.b)), dim3(256), 0, st, G, ws->Vr, corr, nc, n - 1);
+      double* Xn = ws->Xa;  // chi_{j+1}
+      double* Xc = ws->Xb;  // chi_j
+      for (int j = n - 2; j >= 0; --j) {
+        BTRY(hipMemcpyAsync(ws->Y, ws->hR + (long long)j * nc * sx, 8ll * nc * sx, hipMemcpyDeviceToDevice, st));
+        gemm(c, false, false, 16, Bp, Bp, -1.0, ws->Vr, Bp, sx, ws->hW + (long long)j * nc * mat, Bp, mat, 1.0, ws->Y, Bp, sx);
+        if (j < n - 2) right_mult_Et(c, Xn, ws->Y, 16, j, -1.0, +1, 1);  // Y -= chi_{j+1} E_j  (E_j[r][c] = K[(c, j), (r, j+1)])
+        gemm(c, false, false, 16, Bp, Bp, 1.0, ws->Y, Bp, sx, ws->hS + (long long)j * nc * mat, Bp, mat, 0.0, Xc, Bp, sx);
+        hipLaunchKernelGGL(k_store_corr, dim3(nblk(nc * (long long)G.t * G.b)), dim3(256), 0, st, G, Xc, corr, nc, j);
+        std::swap(Xn, Xc);
+      }
+      hipLaunchKernelGGL(k_center_corr, dim3((unsigned)(nc * G.t)), dim3(256), 0, st, G, corr);
+    }
     // ---- K3
     hipLaunchKernelGGL(k_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, G, ws->C0, ws->Gm, d_out + c0 * G.t * G.t, nc);
     BTRY(hipGetLastError());

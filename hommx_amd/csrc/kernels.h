@@ -20,6 +20,6 @@ struct BlockedWorkspace;
 int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind);
 void blocked_workspace_destroy(BlockedWorkspace* ws);
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M,
-                  double* d_out, int32_t* d_info, hipStream_t stream);
+                  double* d_out, int32_t* d_info, hipStream_t stream, double* d_corr = nullptr);
 const char* blocked_last_error();
 }  // namespace hommx

@@ -318,6 +318,44 @@ class BaseHMM(ABC):
         AH, info = self._effective_tensors(cells)
         return self._local_stiffness_from_tensors(cells, AH)[0]
 
+    def _periodic_to_micro_nodes(self) -> np.ndarray:
+        """Micro-mesh node -> periodic unknown (the slave -> master map of cell_problem.py:38-300 on the torus)."""
+        n, d = self._n_micro, self._tdim
+        g = np.rint(self._cell_mesh.geometry.x[:, :d] * n).astype(np.int64) % n
+        return g @ (n ** np.arange(d))
+
+    def correctors_for_cell(self, cell_index: int) -> list[fem.Function]:
+        """The nb correctors of one macro cell as functions on the micro mesh -- what the reference leaves in
+        ``self._correctors`` after ``_compute_local_stiffness(cell_index)`` (hmm.py:204-207, 354-358, 431).
+
+        Computed from the canonical correctors chi_m returned by the GPU: the macro basis functions are affine on the
+        sampling box, so corrector_i = eps * sum_m w_m(grad phi_i) chi_m, up to the additive constant
+        the reference's Krylov solve leaves undetermined (returned mean-free)."""
+        cells = np.array([cell_index])
+        coef, kind = self._element_means(cells)
+        M = self._stratification(cells)
+        if self._plan is None or self._plan.kind != kind:
+            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
+        _, chi = self._plan.solve(coef, M, return_correctors=True)  # [1, t, n^d * bs]
+        d, bs = self._tdim, self._bs
+        X = self._msh.cell_vertices()[cells][0]
+        G = np.linalg.inv(np.concatenate([np.ones((d + 1, 1)), X], axis=1))[1:, :].T  # grad phi_a
+        if bs == 1:
+            Wv = G  # [nb, t = d]
+        else:
+            I = np.eye(d)
+            eps_ = 0.5 * (np.einsum("pi,aj->apij", I, G) + np.einsum("pj,ai->apij", I, G)).reshape((d + 1) * bs, d, d)
+            Wv = np.stack([eps_[:, k, l] * (1.0 if k == l else 2.0) for (k, l) in _VOIGT[d]], axis=-1)
+        per = self._eps * (Wv @ chi[0])  # [nb, n^d * bs]
+        idx = self._periodic_to_micro_nodes()
+        V_micro = fem.FunctionSpace(self._cell_mesh, bs)
+        out = []
+        for i in range(per.shape[0]):
+            f = fem.Function(V_micro)
+            f.x.array[:] = per[i].reshape(-1, bs)[idx].ravel()
+            out.append(f)
+        return out
+
     def _assemble_stiffness(self):
         """hmm.py:298-332 with the cell loop replaced by one batched call."""
         if not self._needs_reassembly:
@@ -438,6 +476,7 @@ class PoissonPeriodicHMM:
                                  petsc_options_cell_problem, petsc_options_prefix, **kw)
         self._inner._bcs = []
         self._A_hom = None
+        self._correctors = None
 
     @property
     def function_space(self):
@@ -453,11 +492,31 @@ class PoissonPeriodicHMM:
     def set_right_hand_side(self, f):
         self._inner.set_right_hand_side(f)
 
+    @property
+    def correctors(self) -> list[fem.Function]:
+        """One corrector per direction e_q on the micro mesh (hmm.py:1211-1213, filled by compute_effective_tensor :1239-1240)."""
+        if self._correctors is None:
+            self.compute_effective_tensor()
+        return self._correctors
+
     def compute_effective_tensor(self) -> np.ndarray:
-        AH, info = self._inner._effective_tensors(np.array([0]))
+        """hmm.py:1219-1245: one periodic cell problem per direction -> correctors and A_hom (a batch of ONE on the GPU)."""
+        h = self._inner
+        cells = np.array([0])
+        coef, kind = h._element_means(cells)
+        if h._plan is None or h._plan.kind != kind:
+            h._plan = MicroCellPlan(h._tdim, h._n_micro, kind, device=h._device)
+        AH, chi, info = h._plan.solve(coef, None, return_info=True, return_correctors=True)
         if info[0]:
-            self._inner._logger.error("Something went wrong in the cell problem solving for the periodic cell")
+            h._logger.error("Something went wrong in the cell problem solving for the periodic cell")
         self._A_hom = AH[0]
+        idx = h._periodic_to_micro_nodes()
+        V_micro = fem.FunctionSpace(h._cell_mesh, 1)
+        self._correctors = []
+        for q in range(chi.shape[1]):
+            f = fem.Function(V_micro)
+            f.x.array[:] = chi[0, q][idx]
+            self._correctors.append(f)
         return self._A_hom
 
     def solve(self) -> fem.Function:

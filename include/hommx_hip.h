@@ -85,6 +85,17 @@ int hommx_solve_batch(hommx_plan* plan, int64_t n_cells, const double* coef, con
 int hommx_solve_batch_device(hommx_plan* plan, int64_t n_cells, const double* d_coef, const double* d_M,
                              double* d_A_eff, int32_t* d_info, void* stream);
 
+/* Same as hommx_solve_batch, additionally returning the correctors (host pointers):
+ *   correctors [n_cells][t][n^d * bs]  chi_m of the canonical load case m (unit gradient e_m / unit strain E^m) at the
+ *                                      periodic unknowns, dof = node * bs + component, node = i + n j [+ n^2 k];
+ *                                      mean-free per component (the reference removes the constants: cell_problem.py:349-361).
+ * These are the functions the reference keeps in self._correctors (hmm.py:204-207, 431) / PoissonPeriodicHMM.correctors
+ * (hmm.py:1211-1213, 1239-1240), for the canonical loads instead of the nb macro basis functions: the corrector of a
+ * macro basis function is the linear combination  eps * sum_m (grad phi_i)_m chi_m  (SURVEY A.2, row A5).
+ * Runs on the blocked kernel family for every plan (the fused 2D kernel never forms the factors). */
+int hommx_solve_batch_correctors(hommx_plan* plan, int64_t n_cells, const double* coef, const double* M,
+                                 double* A_eff, double* correctors, int32_t* info);
+
 /* Calibration micro-benchmark: sustained fp64 MFMA rate (v_mfma_f64_16x16x4_f64, all CUs), in FLOP/s.
  * Used by bench.py to state the fp64 matrix peak next to the datasheet figure. */
 int hommx_calibrate_fp64_mfma(int device, double* flops_per_s);

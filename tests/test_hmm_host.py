@@ -16,7 +16,7 @@ class OraclePlan:
         self.dim, self.n, self.kind = dim, n, kind
         self.t = dim if kind.startswith("poisson") else dim * (dim + 1) // 2
 
-    def solve(self, coef, M=None, return_info=False):
+    def solve(self, coef, M=None, return_info=False, return_correctors=False):
         okind = "poisson" if self.kind.startswith("poisson") else "elasticity"
         c = coef
         if self.kind == "poisson_matrix":
@@ -29,7 +29,17 @@ class OraclePlan:
         if self.kind == "elasticity_voigt":
             raise NotImplementedError
         out = O.effective_tensor_batch(okind, self.dim, self.n, c, M)
-        return (out, np.zeros(len(coef), np.int32)) if return_info else out
+        info = np.zeros(len(coef), np.int32)
+        if return_correctors:
+            bs = 1 if okind == "poisson" else self.dim
+            corr = []
+            for k in range(len(coef)):
+                chi = O.solve_correctors(O.build_cell_problem(okind, self.dim, self.n, c[k], None if M is None else M[k])).T
+                x = chi.reshape(chi.shape[0], -1, bs)
+                corr.append((x - x.mean(axis=1, keepdims=True)).reshape(chi.shape))
+            corr = np.stack(corr)
+            return (out, corr, info) if return_info else (out, corr)
+        return (out, info) if return_info else out
 
 
 def with_oracle(h):
