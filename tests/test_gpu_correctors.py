@@ -68,3 +68,25 @@ def test_periodic_hmm_correctors_and_macro_basis_correctors():
     for i, f in enumerate(cs):
         ref = 0.05 * (chi - chi.mean(axis=0)) @ G[i]
         assert np.abs(f.x.array - ref[pm]).max() < 1e-10
+
+
+def test_periodic_linear_problem_front_end(rng):
+    """hommx_amd.cell_problem.PeriodicLinearProblem: one cell problem, all canonical loads, functions on the micro mesh."""
+    from hommx_amd import fem, mesh
+    from hommx_amd.cell_problem import PeriodicLinearProblem, create_periodic_boundary_conditions
+    from oracle import hommx_oracle as O
+
+    n = 9
+    mic = mesh.create_unit_square(n, n)
+    V = fem.functionspace(mic, ("Lagrange", 1))
+    mpc = create_periodic_boundary_conditions(V)
+    coef = rng.uniform(0.2, 3.0, 2 * n * n)
+    prob = PeriodicLinearProblem("poisson", coef, mpc)
+    sols = prob.solve()
+    cp = O.build_cell_problem("poisson", 2, n, coef)
+    assert prob.info == 0 and np.abs(prob.effective_tensor - O.effective_tensor(cp)).max() < 1e-12
+    chi = O.solve_correctors(cp)
+    for m, f in enumerate(sols):
+        ref = (chi[:, m] - chi[:, m].mean())[mpc.to_periodic]
+        assert np.abs(f.x.array - ref).max() < 1e-10
+        assert np.array_equal(f.x.array[mpc.slaves], f.x.array[mpc.masters])  # u(x, 1) = u(x, 0) etc.
