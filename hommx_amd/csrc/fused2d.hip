@@ -36,12 +36,6 @@
 #ifndef HOMMX_FUSED_WAVES_PER_SIMD
 #define HOMMX_FUSED_WAVES_PER_SIMD 2
 #endif
-#ifndef HOMMX_FUSED_STAGGER
-#define HOMMX_FUSED_STAGGER 0
-#endif
-#ifndef HOMMX_FUSED_PARK_W
-#define HOMMX_FUSED_PARK_W 1
-#endif
 
 namespace hommx {
 
@@ -69,8 +63,7 @@ struct CoefRow {
 template <int NB>
 struct alignas(16) Lds {
   double mat[NB * NB];   // N = -S^-1 (symmetric, swizzled) / band-matrix indexer / S_last transfer
-  double ubuf[NB];       // sweep: raw pivot row
-  double wbuf[NB];       // sweep: scaled pivot row
+  double ubuf[NB];       // sweep: raw pivot row (published one pivot ahead)
   double rbuf[2][NB];    // R rows of the current block
   double vrbuf[2][NB];   // Vr' = R N
   double e0[NB];         // E[r][r]
@@ -226,18 +219,6 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     rr[0] = st_p0(cur, rowB); rr[1] = st_p1(cur, rowB);    // R_0
     rl[0] = st_p0(rowB, rowA); rl[1] = st_p1(rowB, rowA);  // R_last
   }
-#if HOMMX_FUSED_STAGGER
-  // The two waves that share a SIMD run the same program; left alone they reach the VALU-bound sweep and the
-  // MFMA-bound products together.  Delaying the odd hardware wave slot by about half a block step puts one
-  // wave's matrix products beside the other's sweep (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-  {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hwid));
-    if (hwid & 1) {
-      for (int q = 0; q < HOMMX_FUSED_STAGGER; ++q) __builtin_amdgcn_s_sleep(127);
-    }
-  }
-#endif
   double g00 = 0.0, g01 = 0.0, g11 = 0.0;  // -G partial sums (every lane group holds a copy)
   int bad = 0, badstep = 0;
   const int kq = (n - 1) >> 2, lq = (n - 1) & 3;  // where column n-1 lives in operand layout
@@ -271,27 +252,11 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       L.e1[c] = e1c;
     }
 
-    // (1) N = -S^-1.  The matrix buffer is idle during the sweep: W is parked there (own lane's slots, no
-    //     cross-lane traffic) so that its 2*NT*KK registers are free while the sweep holds S and the pivot row.
-#if HOMMX_FUSED_PARK_W
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) L.mat[(t * KK + kk) * 64 + l] = wf[t][kk];
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    // (1) N = -S^-1
 #ifndef HOMMX_ABLATE_SWEEP
     int badj = 0;
-    sweep_blk<NB>(s, L.ubuf, L.wbuf, bi, bj, badj);
+    sweep_blk<NB>(s, L.ubuf, bi, bj, badj);
     if (badj && !bad) { bad = 1; badstep = j + 1; }
-#endif
-#if HOMMX_FUSED_PARK_W
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) wf[t][kk] = L.mat[(t * KK + kk) * 64 + l];
-    __syncthreads();
 #endif
 
     // (2) N -> LDS: BS rows of BS consecutive doubles per lane (8 lanes cover one 256-byte matrix row)
@@ -542,7 +507,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   __syncthreads();
   {
     int badj = 0;
-    sweep_blk<NB>(s, L.ubuf, L.wbuf, bi, bj, badj);
+    sweep_blk<NB>(s, L.ubuf, bi, bj, badj);
     if (badj && !bad) { bad = 1; badstep = n; }
 #pragma unroll
     for (int r = 0; r < BS; ++r)

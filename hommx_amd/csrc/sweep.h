@@ -103,81 +103,6 @@ struct SweepStep<NB, NB, SYNC> {
 
 namespace hommx {
 
-// ---- software-pipelined column-strip sweep ----------------------------------------------------------------
-// Same arithmetic as SweepStep, reordered so that one LDS round trip per pivot is the whole critical path:
-//   * the raw pivot row K+1 is written to LDS as soon as ITS entries are updated (first FMA of step K), i.e. a full
-//     step ahead of its use; the rest of the rank-1 update of step K runs in the shadow of that round trip;
-//   * the reciprocal of pivot K+1 (v_rcp_f64 + two Newton steps, ~8 dependent f64 ops) is started at the same
-//     point and is not needed before the row has come back;
-//   * the pivot column is refreshed by a predicated LDS read whose wait merges with the next step's.
-template <int NB, int K>
-struct SweepStepP {
-  static __device__ __forceinline__ void run(double (&s)[Cfg<NB>::RPL], double* __restrict__ ubuf,
-                                             double* __restrict__ wbuf, int c, int g, int r0, int& bad, double d,
-                                             double pinv) {
-    constexpr int RPL = Cfg<NB>::RPL;
-    constexpr int gk = K / RPL, ik = K % RPL;
-    constexpr bool more = (K + 1 < NB);
-    constexpr int K1 = more ? K + 1 : K;
-    constexpr int gk1 = K1 / RPL, ik1 = K1 % RPL;
-    bad |= !(d > 0.0);
-    __syncthreads();  // pivot row K (written one step ago) and the previous pivot-column refresh have landed
-    const double uc = ubuf[c];
-    double x[RPL];
-#pragma unroll
-    for (int i = 0; i < RPL; i += 2) {
-      const double2 t2 = *reinterpret_cast<const double2*>(&ubuf[r0 + i]);
-      x[i] = t2.x;
-      x[i + 1] = t2.y;
-    }
-    const double t = (c == K) ? -pinv : uc * pinv;  // scaled pivot row entry of my column
-    double dn = 1.0, pn = 1.0;
-    if (more) {
-      // pivot row K+1 first: update, publish raw, start its reciprocal
-      double e = fma(-x[ik1], t, s[ik1]);
-      if (c == K) e = x[ik1] * pinv;  // its entry in the pivot column K
-      s[ik1] = e;
-      if (g == gk1) ubuf[c] = e;
-      dn = readlane_f64(e, gk1 * NB + K1);
-      pn = pin_here(fast_rcp(dn));  // keep the reciprocal chain HERE (the compiler would sink it to its first use)
-    }
-#pragma unroll
-    for (int i = 0; i < RPL; ++i)
-      if (!(more && i == ik1)) s[i] = fma(-x[i], t, s[i]);
-    if (g == gk) {
-      wbuf[c] = t;
-      s[ik] = t;  // pivot row
-    }
-    if (c == K) {  // pivot column := scaled pivot row (symmetry); the LDS pipeline is in-order per wave
-#pragma unroll
-      for (int i = 0; i < RPL; i += 2) {
-        const double2 t2 = *reinterpret_cast<const double2*>(&wbuf[r0 + i]);
-        s[i] = t2.x;
-        s[i + 1] = t2.y;
-      }
-    }
-    SweepStepP<NB, K + 1>::run(s, ubuf, wbuf, c, g, r0, bad, dn, pn);
-  }
-};
-template <int NB>
-struct SweepStepP<NB, NB> {
-  static __device__ __forceinline__ void run(double (&)[Cfg<NB>::RPL], double*, double*, int, int, int, int&, double,
-                                             double) {}
-};
-
-template <int NB>
-__device__ __forceinline__ void sweep_strip_pipelined(double (&s)[Cfg<NB>::RPL], double* ubuf, double* wbuf, int c,
-                                                      int g, int r0, int& bad) {
-  if (g == 0) ubuf[c] = s[0];  // raw pivot row 0
-  const double d0 = readlane_f64(s[0], 0);
-  SweepStepP<NB, 0>::run(s, ubuf, wbuf, c, g, r0, bad, d0, fast_rcp(d0));
-  __syncthreads();  // the last pivot-column refresh
-}
-
-}  // namespace hommx
-
-namespace hommx {
-
 // ---- same sweep, "BLK layout": lane l owns the BS x BS block (bi = l >> 3, bj = l & 7), BS = NB / 8 ----------
 // Element (r, q) of the block is matrix entry (BS*bi + r, BS*bj + q) and lives in s[r * BS + q].
 // Per pivot a lane needs only BS entries of the pivot row for its rows and BS for its columns (2*BS LDS
@@ -214,8 +139,6 @@ struct SweepStepBlk {
 #pragma unroll
       for (int q = 0; q < BS; ++q) e[q] = fma(-t[kr1], uc[q], s[kr1 * BS + q]);
       if (bj == kb) e[kr] = t[kr1];
-      if (bi == kb && kb1 == kb) {  // row K+1 lies in the pivot row's block row: nothing special (row K is fixed below)
-      }
 #pragma unroll
       for (int q = 0; q < BS; ++q) s[kr1 * BS + q] = e[q];
       if (bi == kb1) {
@@ -251,8 +174,8 @@ struct SweepStepBlk<NB, NB> {
 
 // entry: pivot 0 and its reciprocal, then the pipelined steps
 template <int NB>
-__device__ __forceinline__ void sweep_blk(double (&s)[(NB / 8) * (NB / 8)], double* ubuf, double* wbuf, int bi,
-                                          int bj, int& bad) {
+__device__ __forceinline__ void sweep_blk(double (&s)[(NB / 8) * (NB / 8)], double* ubuf, int bi, int bj,
+                                          int& bad) {
   constexpr int BS = NB / 8;
   if (bi == 0) {
 #pragma unroll
@@ -260,7 +183,6 @@ __device__ __forceinline__ void sweep_blk(double (&s)[(NB / 8) * (NB / 8)], doub
   }
   const double d0 = readlane_f64(s[0], 0);
   SweepStepBlk<NB, 0>::run(s, ubuf, bi, bj, bad, d0, fast_rcp(d0));
-  (void)wbuf;
 }
 
 }  // namespace hommx
