@@ -173,3 +173,24 @@ def test_info_reports_bad_cells():
     coef[1, :, 1] = -1.0  # negative shear modulus: not SPD
     A, info = plan(3, n, "elasticity").solve(coef, return_info=True)
     assert info[0] == 0 and info[2] == 0 and info[1] > 0
+
+
+def test_2d_poisson_beyond_the_fused_family(rng, O):
+    """n_micro = 40 > 32: the plan falls back to the blocked family (b = 40, Bp = 64)."""
+    n, nc = 40, 3
+    coef = np.exp(rng.uniform(np.log(0.05), np.log(5.0), size=(nc, 2 * n * n)))
+    M = np.eye(2)[None] + 0.3 * rng.standard_normal((nc, 2, 2))
+    p = plan(2, n, "poisson")
+    assert p.kernel == "blocked"
+    assert relerr(p.solve(coef, M), O.effective_tensor_batch("poisson", 2, n, coef, M)) < TOL
+
+
+def test_bitwise_reproducible(rng):
+    """No atomics, fixed reduction order: two runs of either family give identical bits."""
+    n = 32
+    coef = rng.uniform(0.1, 3.0, size=(64, 2 * n * n))
+    p = plan(2, n, "poisson")
+    assert np.array_equal(p.solve(coef), p.solve(coef))
+    coef3 = np.stack([rng.uniform(0.5, 2.0, (4, 6 * 4**3)), rng.uniform(0.1, 10.0, (4, 6 * 4**3))], axis=-1)
+    q = plan(3, 4, "elasticity")
+    assert np.array_equal(q.solve(coef3), q.solve(coef3))
