@@ -88,60 +88,140 @@ __device__ __forceinline__ void element_matrix(const Geo& G, const double* c, do
   }
 }
 
-__global__ void k_assemble(Geo G, const double* __restrict__ coef, const double* __restrict__ Mmat,
-                           double* __restrict__ Kst, double* __restrict__ Brhs, long long ncells) {
+// compile-time variants of the two helpers above (everything stays in registers, loops unroll)
+template <int D, int BSV, int T>
+__device__ __forceinline__ void strain_weights_ct(const double* g, int alpha, double* w) {
+  if (BSV == 1) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) w[k] = g[k];
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) w[k] = (k == alpha) ? g[k] : 0.0;
+  int m = D;
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int l = k + 1; l < D; ++l, ++m) w[m] = (k == alpha ? g[l] : 0.0) + (l == alpha ? g[k] : 0.0);
+}
+
+template <int D, int KIND, int T>
+__device__ __forceinline__ void element_matrix_ct(const double* c, double* Cv) {
+#pragma unroll
+  for (int i = 0; i < T * T; ++i) Cv[i] = 0.0;
+  if (KIND == HOMMX_KIND_POISSON_SCALAR) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) Cv[k * T + k] = c[0];
+  } else if (KIND == HOMMX_KIND_POISSON_MATRIX) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) Cv[k * T + k] = c[k];
+    int m = D;
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+#pragma unroll
+      for (int l = k + 1; l < D; ++l, ++m) Cv[k * T + l] = Cv[l * T + k] = c[m];
+  } else if (KIND == HOMMX_KIND_ELASTICITY_ISO) {
+    const double lam = c[0], mu = c[1];
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+#pragma unroll
+      for (int l = 0; l < D; ++l) Cv[k * T + l] = lam + (k == l ? 2.0 * mu : 0.0);
+#pragma unroll
+    for (int m = D; m < T; ++m) Cv[m * T + m] = mu;
+  } else {
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < T; ++k)
+#pragma unroll
+      for (int l = k; l < T; ++l, ++q) Cv[k * T + l] = Cv[l * T + k] = c[q];
+  }
+}
+
+// One thread per (cell, node): gather the (d+1) * n_sub incident elements into the node's stencil rows.
+template <int D, int KIND>
+__global__ __launch_bounds__(128) void k_assemble(Geo G, const double* __restrict__ coef,
+                                                  const double* __restrict__ Mmat, double* __restrict__ Kst,
+                                                  double* __restrict__ Brhs, long long ncells) {
+  constexpr bool EL = KIND >= HOMMX_KIND_ELASTICITY_ISO;
+  constexpr int BSV = EL ? D : 1, T = EL ? D * (D + 1) / 2 : D, NV = D + 1, NSUB = (D == 2) ? 2 : 6;
+  constexpr int NCOMP = KIND == HOMMX_KIND_POISSON_SCALAR ? 1
+                        : KIND == HOMMX_KIND_POISSON_MATRIX ? D * (D + 1) / 2
+                        : KIND == HOMMX_KIND_ELASTICITY_ISO ? 2
+                                                            : T * (T + 1) / 2;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ncells * G.nn) return;
   const long long cell = idx / G.nn;
   const int node = (int)(idx % G.nn);
-  const int d = G.dim, n = G.n, bs = G.bs, t = G.t;
-  int pc[3] = {node % n, (node / n) % n, d == 3 ? node / (n * n) : 0};
-  double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (Mmat) {
-    for (int i = 0; i < d; ++i)
-      for (int j = 0; j < d; ++j) M[i * 3 + j] = Mmat[cell * d * d + i * d + j];
-  }
+  const int n = G.n;
+  int pc[3] = {node % n, (node / n) % n, D == 3 ? node / (n * n) : 0};
+  double M[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) M[i][j] = Mmat ? Mmat[cell * D * D + i * D + j] : (i == j ? 1.0 : 0.0);
   double vol = 1.0;
-  for (int k = 0; k < d; ++k) vol /= n;
-  vol /= (d == 2 ? 2.0 : 6.0);
-  const double* ccell = coef + cell * (long long)G.n_el * G.ncomp;
-  double* Kc = Kst + cell * (long long)G.ncode * bs * bs * G.nn;
-  double* Bc = Brhs + cell * (long long)t * bs * G.nn;
-  const int nv = d + 1;
-  for (int s = 0; s < G.nsub; ++s) {
-    for (int a = 0; a < nv; ++a) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) vol /= n;
+  vol /= (D == 2 ? 2.0 : 6.0);
+  const double* ccell = coef + cell * (long long)G.n_el * NCOMP;
+  double* Kc = Kst + cell * (long long)G.ncode * BSV * BSV * G.nn;
+  double* Bc = Brhs + cell * (long long)T * BSV * G.nn;
+  for (int s = 0; s < NSUB; ++s) {
+    for (int a = 0; a < NV; ++a) {
       // the cell whose sub-element s has its local vertex a at this node
-      int cc[3];
-      for (int k = 0; k < 3; ++k) cc[k] = 0;
-      for (int k = 0; k < d; ++k) cc[k] = (pc[k] - G.voff[s][a][k] + n) % n;
-      const long long e = (long long)G.nsub * (cc[0] + n * (cc[1] + (long long)n * cc[2])) + s;
-      double Cv[36];
-      element_matrix(G, ccell + e * G.ncomp, Cv);
-      double gt[4][3];  // g~_b = M (n grad_b)
-      for (int b = 0; b < nv; ++b)
-        for (int i = 0; i < d; ++i) {
+      int cc[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        int v = pc[k] - G.voff[s][a][k];
+        cc[k] = v < 0 ? v + n : v;
+      }
+      const long long e = (long long)NSUB * (cc[0] + n * (cc[1] + (long long)n * cc[2])) + s;
+      double cval[NCOMP];
+#pragma unroll
+      for (int q = 0; q < NCOMP; ++q) cval[q] = ccell[e * NCOMP + q];
+      double Cv[T * T];
+      element_matrix_ct<D, KIND, T>(cval, Cv);
+      double gt[NV][D];  // g~_b = M (n grad_b)
+#pragma unroll
+      for (int b = 0; b < NV; ++b)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
           double acc = 0.0;
-          for (int k = 0; k < d; ++k) acc += M[i * 3 + k] * G.grad[s][b][k];
+#pragma unroll
+          for (int k = 0; k < D; ++k) acc += M[i][k] * G.grad[s][b][k];
           gt[b][i] = acc * n;
         }
-      for (int al = 0; al < bs; ++al) {
-        double w[6], y[6];
-        strain_weights(G, gt[a], al, w);
-        for (int m = 0; m < t; ++m) {
+      int code[NV];
+#pragma unroll
+      for (int b = 0; b < NV; ++b) {
+        int cd = 0, p3 = 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k, p3 *= 3) cd += (G.voff[s][b][k] - G.voff[s][a][k] + 1) * p3;
+        code[b] = cd;
+      }
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) {
+        double w[T], y[T];
+        strain_weights_ct<D, BSV, T>(gt[a], al, w);
+#pragma unroll
+        for (int m = 0; m < T; ++m) {
           double acc = 0.0;
-          for (int q = 0; q < t; ++q) acc += Cv[m * t + q] * w[q];
+#pragma unroll
+          for (int q = 0; q < T; ++q) acc += Cv[m * T + q] * w[q];
           y[m] = vol * acc;
         }
-        for (int m = 0; m < t; ++m) Bc[((long long)m * bs + al) * G.nn + node] -= y[m];
-        for (int b = 0; b < nv; ++b) {
-          int code = 0, p3 = 1;
-          for (int k = 0; k < d; ++k, p3 *= 3) code += (G.voff[s][b][k] - G.voff[s][a][k] + 1) * p3;
-          for (int be = 0; be < bs; ++be) {
-            double wb[6];
-            strain_weights(G, gt[b], be, wb);
+#pragma unroll
+        for (int m = 0; m < T; ++m) Bc[((long long)m * BSV + al) * G.nn + node] -= y[m];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+#pragma unroll
+          for (int be = 0; be < BSV; ++be) {
+            double wb[T];
+            strain_weights_ct<D, BSV, T>(gt[b], be, wb);
             double acc = 0.0;
-            for (int m = 0; m < t; ++m) acc += y[m] * wb[m];
-            Kc[(((long long)code * bs + al) * bs + be) * G.nn + node] += acc;
+#pragma unroll
+            for (int m = 0; m < T; ++m) acc += y[m] * wb[m];
+            Kc[(((long long)code[b] * BSV + al) * BSV + be) * G.nn + node] += acc;
           }
         }
       }
@@ -780,7 +860,16 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     // ---- K1
     BTRY(hipMemsetAsync(ws->Kst, 0, 8ll * nc * G.ncode * G.bs * G.bs * G.nn, st));
     BTRY(hipMemsetAsync(ws->Brhs, 0, 8ll * nc * G.t * G.bs * G.nn, st));
-    hipLaunchKernelGGL(k_assemble, dim3(nblk(nc * G.nn, 128)), dim3(128), 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc);
+    {
+      dim3 ag(nblk(nc * G.nn, 128)), ab(128);
+#define HOMMX_ASM(D_, K_) hipLaunchKernelGGL((k_assemble<D_, K_>), ag, ab, 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc)
+      if (G.dim == 2) {
+        if (G.kind == 0) HOMMX_ASM(2, 0); else if (G.kind == 1) HOMMX_ASM(2, 1); else if (G.kind == 2) HOMMX_ASM(2, 2); else HOMMX_ASM(2, 3);
+      } else {
+        if (G.kind == 0) HOMMX_ASM(3, 0); else if (G.kind == 1) HOMMX_ASM(3, 1); else if (G.kind == 2) HOMMX_ASM(3, 2); else HOMMX_ASM(3, 3);
+      }
+#undef HOMMX_ASM
+    }
     hipLaunchKernelGGL(k_c0, dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0);
     // ---- K2 init
     BTRY(hipMemsetAsync(ws->S, 0, 8ll * nc * mat, st));
