@@ -304,34 +304,39 @@ __global__ void k_scatter_plane(Geo G, const double* __restrict__ Kst, double* _
 // o = -1 (codeOff = 0, the elimination) or +1 (codeOff = 2 * 3^(d-1), the back substitution).
 // One thread per output column c and tile of RT rows k: the NE = bs * 3^(d-1) entries of E row c and their
 // column indices are gathered once into registers and reused for every row of the tile.
-template <int NE, int RT>
+// One thread per NODE q (its BSV output columns c = q BSV + al) and tile of RT rows k: the BSV x NE entries of E and
+// the NE column indices are gathered once into registers; per row every input IN[k][k'] is loaded once and feeds
+// the BSV outputs of the node.
+template <int BSV, int NE, int RT>
 __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __restrict__ Kst,
                                                        const double* __restrict__ IN, double* __restrict__ OUT,
                                                        int nrows, int rowPlane, double alpha, int codeOff,
                                                        int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= G.Bp) return;
+  const int q = blockIdx.x * 256 + threadIdx.x;  // node in plane (or padding)
+  if (q * BSV >= G.Bp) return;
   const long long cell = blockIdx.z;
   const int k0 = blockIdx.y * RT;
   const long long per = (long long)nrows * G.Bp;
-  double e[NE];
+  double e[BSV][NE];
   int kx[NE];
+  const bool real = q < G.npl;
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
-    e[j] = 0.0;
     kx[j] = 0;
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) e[al][j] = 0.0;
   }
-  if (c < G.b) {
+  if (real) {
     const int nipc = G.ncode / 3;
-    const int q = c / G.bs, al = c % G.bs;
     const int node = q + G.npl * rowPlane;
-    const double* kb = Kst + ((cell * G.ncode) * G.bs + al) * G.bs * (long long)G.nn + node;
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      const int ipc = j / G.bs, be = j % G.bs;
+      const int ipc = j / BSV, be = j % BSV;
       if (ipc < nipc) {
-        e[j] = kb[((long long)(ipc + codeOff) * G.bs * G.bs + be) * G.nn];
-        kx[j] = plane_neighbour(G, q, ipc) * G.bs + be;
+        kx[j] = plane_neighbour(G, q, ipc) * BSV + be;
+#pragma unroll
+        for (int al = 0; al < BSV; ++al)
+          e[al][j] = Kst[((cell * G.ncode + ipc + codeOff) * BSV + al) * BSV * (long long)G.nn + (long long)be * G.nn + node];
       }
     }
   }
@@ -340,11 +345,23 @@ __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __re
   const int k1 = min(nrows, k0 + RT);
   for (int k = k0; k < k1; ++k) {
     const double* row = in + (long long)k * G.Bp;
-    double acc = 0.0;
+    double acc[BSV];
 #pragma unroll
-    for (int j = 0; j < NE; ++j) acc = fma(row[kx[j]], e[j], acc);
-    double* o = out + (long long)k * G.Bp + c;
-    *o = accumulate ? *o + alpha * acc : alpha * acc;
+    for (int al = 0; al < BSV; ++al) acc[al] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const double v = row[kx[j]];
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) acc[al] = fma(v, e[al][j], acc[al]);
+    }
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) {
+      const int c = q * BSV + al;
+      if (c < G.Bp) {
+        double* o = out + (long long)k * G.Bp + c;
+        *o = accumulate ? *o + alpha * acc[al] : alpha * acc[al];
+      }
+    }
   }
 }
 
@@ -789,14 +806,15 @@ void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int r
                    int olast = -1, int accumulate = 0) {
   const Geo& G = c.ws->G;
   constexpr int RT = 32;
-  dim3 grid((G.Bp + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
+  const int nodes = (G.Bp + G.bs - 1) / G.bs;
+  dim3 grid((nodes + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
   const int codeOff = (olast + 1) * (G.ncode / 3);
-#define HOMMX_RM(NE) hipLaunchKernelGGL((k_right_mult_Et<NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate)
-  if (ne == 3) HOMMX_RM(3);
-  else if (ne == 6) HOMMX_RM(6);
-  else if (ne == 9) HOMMX_RM(9);
-  else HOMMX_RM(27);
+#define HOMMX_RM(BSV, NE) hipLaunchKernelGGL((k_right_mult_Et<BSV, NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate)
+  if (ne == 3) HOMMX_RM(1, 3);
+  else if (ne == 6) HOMMX_RM(2, 6);
+  else if (ne == 9) HOMMX_RM(1, 9);
+  else HOMMX_RM(3, 27);
 #undef HOMMX_RM
 }
 
