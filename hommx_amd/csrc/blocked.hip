@@ -493,7 +493,9 @@ constexpr int GP = 80;  // LDS row pitch (doubles): 160 dwords == 32 mod 64 -> c
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
                                               long long sA, const double* __restrict__ B, int ldb, long long sB,
-                                              double beta, double* __restrict__ C, int ldc, long long sC) {
+                                              double beta, double* __restrict__ C, int ldc, long long sC,
+                                              int lowerOnly) {
+  if (lowerOnly && blockIdx.x > blockIdx.y) return;  // symmetric result: tiles above the diagonal are mirrored later
   __shared__ double As[16 * GP];
   __shared__ double Bs[16 * GP];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
@@ -584,6 +586,17 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha,
           *p = v;
         }
       }
+}
+
+// A[i][j] = A[j][i] for j > i  (mirror the lower triangle; batched, ld = N)
+__global__ void k_symmetrize(int N, double* __restrict__ A, long long sA, long long ncells) {
+  const long long per = (long long)N * N;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const int rem = (int)(idx % per);
+  const int j = rem % N, i = rem / N;
+  if (j > i) A[cell * sA + (long long)i * N + j] = A[cell * sA + (long long)j * N + i];
 }
 
 // OUT[i][j] = IN[j][i]  (sub-blocks, batched)
@@ -790,16 +803,16 @@ struct Ctx {
 inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + bs - 1) / bs); }
 
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
-          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC) {
+          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0) {
   dim3 grid((N + 63) / 64, (M + 63) / 64, (unsigned)c.nc), block(256);
   if (!ta && !tb)
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
   else if (!ta && tb)
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
   else if (ta && !tb)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
   else
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC);
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
 }
 
 void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha,
@@ -853,7 +866,8 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
   double* Xm = tmp;  // s2 x s1, ld = s1, batch stride sS (scratch matrices are Bp x Bp per cell)
   invert(c, S, off, s1, tmp);                                                  // A11 <- A11^-1
   gemm(c, false, false, s2, s1, s1, 1.0, A21, ld, sS, A11, ld, sS, 0.0, Xm, s1, sS);   // Xm = A21 A11^-1
-  gemm(c, false, true, s2, s2, s1, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A22, ld, sS);   // A22 <- A22 - Xm A21^T
+  gemm(c, false, true, s2, s2, s1, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A22, ld, sS, 1);  // A22 <- A22 - Xm A21^T (symmetric: lower tiles;
+                                                                                          //  the recursion below never reads above the diagonal tiles)
   invert(c, S, off + s1, s2, tmp + (long long)s1 * s2);                        // A22 <- (Schur)^-1
   gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sS, 0.0, A21, ld, sS);  // A21 <- -T^-1 Xm
   gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A11, ld, sS);   // A11 <- A11^-1 - Xm^T A21
@@ -913,7 +927,7 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
         BTRY(hipMemcpyAsync(ws->hR + (long long)j * nc * 16 * Bp, ws->R, 8ll * nc * 16 * Bp, hipMemcpyDeviceToDevice, st));
       }
       gemm(c, false, false, Bp, Bp, Bp, 1.0, ws->W, Bp, mat, ws->S, Bp, mat, 0.0, ws->V, Bp, mat);      // V = W Sinv
-      gemm(c, false, true, Bp, Bp, Bp, -1.0, ws->V, Bp, mat, ws->W, Bp, mat, 1.0, ws->Sl, Bp, mat);     // S_last -= V W^T
+      gemm(c, false, true, Bp, Bp, Bp, -1.0, ws->V, Bp, mat, ws->W, Bp, mat, 1.0, ws->Sl, Bp, mat, 1);  // S_last -= V W^T (lower tiles)
       gemm(c, false, false, 16, Bp, Bp, 1.0, ws->R, Bp, 16ll * Bp, ws->S, Bp, mat, 0.0, ws->Vr, Bp, 16ll * Bp);   // Vr = R Sinv
       gemm(c, false, true, 16, 16, Bp, 1.0, ws->Vr, Bp, 16ll * Bp, ws->R, Bp, 16ll * Bp, 1.0, ws->Gm, 16, 256);   // G += Vr R^T
       gemm(c, false, true, 16, Bp, Bp, -1.0, ws->Vr, Bp, 16ll * Bp, ws->W, Bp, mat, 1.0, ws->Rl, Bp, 16ll * Bp);  // R_last -= Vr W^T
@@ -928,6 +942,7 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     }
     // ---- last plane
     c.stepcode = n;
+    hipLaunchKernelGGL(k_symmetrize, dim3(nblk(nc * mat)), dim3(256), 0, st, Bp, ws->Sl, mat, nc);  // mirror the lower tiles
     hipLaunchKernelGGL(k_pin_last, dim3(nblk(nc * (long long)Bp * G.bs)), dim3(256), 0, st, G, ws->Sl, ws->Rl, nc);
     invert(c, ws->Sl, 0, Bp, ws->T);
     gemm(c, false, false, 16, Bp, Bp, 1.0, ws->Rl, Bp, 16ll * Bp, ws->Sl, Bp, mat, 0.0, ws->Vr, Bp, 16ll * Bp);
