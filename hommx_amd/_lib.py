@@ -24,6 +24,8 @@ EXPORTED_SYMBOLS = (
     "hommx_solve_batch",
     "hommx_solve_batch_device",
     "hommx_solve_batch_correctors",
+    "hommx_solve_batch_two_phase",
+    "hommx_solve_batch_two_phase_device",
     "hommx_calibrate_fp64_mfma",
     "hommx_last_error",
 )
@@ -87,6 +89,10 @@ def load():
     lib.hommx_solve_batch_device.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.hommx_solve_batch_correctors.restype = C.c_int
     lib.hommx_solve_batch_correctors.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.hommx_solve_batch_two_phase.restype = C.c_int
+    lib.hommx_solve_batch_two_phase.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.hommx_solve_batch_two_phase_device.restype = C.c_int
+    lib.hommx_solve_batch_two_phase_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.hommx_calibrate_fp64_mfma.restype = C.c_int
     lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
     lib.hommx_last_error.restype = C.c_char_p

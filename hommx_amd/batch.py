@@ -92,6 +92,43 @@ class MicroCellPlan:
             )
         return (out, info) if return_info else out
 
+    def solve_two_phase(self, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None = None,
+                        return_info: bool = False):
+        """Two-phase media sampled on the device: mask[n_el] (bool / uint8, phase of every micro element) and
+        values[N_c, 2(, n_comp)] = coefficient of phase 0 / phase 1 at every macro cell -> A_eff[N_c, t, t]."""
+        mask = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if mask.shape != (self.n_el,):
+            raise ValueError(f"mask has shape {mask.shape}; expected ({self.n_el},)")
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        nc = values.shape[0]
+        if values.size != nc * 2 * self.n_comp:
+            raise ValueError(f"values has shape {values.shape}; expected ({nc}, 2" + (f", {self.n_comp})" if self.n_comp > 1 else ")"))
+        Mp = None
+        if M is not None:
+            M = np.ascontiguousarray(M, dtype=np.float64)
+            if M.shape != (nc, self.dim, self.dim):
+                raise ValueError(f"M has shape {M.shape}; expected ({nc}, {self.dim}, {self.dim})")
+            Mp = M.ctypes.data
+        out = np.empty((nc, self.t, self.t), dtype=np.float64)
+        info = np.zeros(nc, dtype=np.int32)
+        if nc:
+            _lib.check(
+                self._lib.hommx_solve_batch_two_phase(
+                    self._h, nc, mask.ctypes.data, values.ctypes.data, Mp, out.ctypes.data, info.ctypes.data
+                ),
+                "hommx_solve_batch_two_phase",
+            )
+        return (out, info) if return_info else out
+
+    def solve_two_phase_device(self, n_cells: int, mask_ptr: int, values_ptr: int, M_ptr: int | None, out_ptr: int,
+                               info_ptr: int | None, stream: int | None = None):
+        _lib.check(
+            self._lib.hommx_solve_batch_two_phase_device(
+                self._h, int(n_cells), mask_ptr, values_ptr, M_ptr or None, out_ptr, info_ptr or None, stream or None
+            ),
+            "hommx_solve_batch_two_phase_device",
+        )
+
     # -- device pointers (torch tensors or raw ints), asynchronous --------------------------------
     def solve_device(self, n_cells: int, coef_ptr: int, M_ptr: int | None, out_ptr: int, info_ptr: int | None,
                      stream: int | None = None):

@@ -52,6 +52,8 @@ struct hommx_plan {
   int32_t* d_info = nullptr;
   int64_t cap_cells = 0;
   hommx::BlockedWorkspace* ws = nullptr;
+  double* d_expand = nullptr;  // two-phase media on the blocked family: expanded element stream
+  int64_t cap_expand = 0;
 };
 
 extern "C" {
@@ -107,6 +109,7 @@ int hommx_plan_destroy(hommx_plan* p) {
   if (p->d_out) hipFree(p->d_out);
   if (p->d_info) hipFree(p->d_info);
   if (p->ws) hommx::blocked_workspace_destroy(p->ws);
+  if (p->d_expand) hipFree(p->d_expand);
   delete p;
   return HOMMX_OK;
 }
@@ -166,6 +169,92 @@ int hommx_solve_batch(hommx_plan* p, int64_t n_cells, const double* coef, const 
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(A_eff, p->d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
   if (info) HIP_TRY(hipMemcpy(info, p->d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
+  return HOMMX_OK;
+}
+
+int hommx_solve_batch_two_phase_device(hommx_plan* p, int64_t n_cells, const uint8_t* d_mask, const double* d_values,
+                                       const double* d_M, double* d_A_eff, int32_t* d_info, void* stream) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (!d_mask || !d_values || !d_A_eff) return fail(HOMMX_EINVAL, "null mask / values / A_eff");
+  if (n_cells > 0x7fffffffll) return fail(HOMMX_EINVAL, "n_cells too large for one launch");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p->family == FAM_FUSED2D) {
+    HIP_TRY(hommx::launch_poisson2d_fused(d_values, d_M, d_A_eff, d_info, p->desc.n_micro, n_cells, st, d_mask));
+    return HOMMX_OK;
+  }
+  // blocked family: expand on the device, chunk by chunk of at most 1 GiB of element stream
+  const int64_t per = p->n_el * p->n_comp;
+  int64_t chunk = (int64_t)((1ll << 27) / (per > 0 ? per : 1));
+  if (chunk < 1) chunk = 1;
+  if (chunk > n_cells) chunk = n_cells;
+  if (chunk > p->cap_expand) {
+    if (p->d_expand) hipFree(p->d_expand);
+    p->d_expand = nullptr;
+    p->cap_expand = 0;
+    HIP_TRY(hipMalloc(&p->d_expand, sizeof(double) * chunk * per));
+    p->cap_expand = chunk;
+  }
+  const int d = p->desc.dim, t = p->t;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+    const int64_t nc = (n_cells - c0 < chunk) ? n_cells - c0 : chunk;
+    HIP_TRY(hommx::launch_expand_two_phase(d_mask, d_values + c0 * 2 * p->n_comp, p->d_expand, p->n_el, p->n_comp, nc, st));
+    int rc = hommx::blocked_solve(p->ws, nc, p->d_expand, d_M ? d_M + c0 * d * d : nullptr, d_A_eff + c0 * t * t,
+                                  d_info ? d_info + c0 : nullptr, st);
+    if (rc != 0) return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+  }
+  return HOMMX_OK;
+}
+
+int hommx_solve_batch_two_phase(hommx_plan* p, int64_t n_cells, const uint8_t* mask, const double* values,
+                                const double* M, double* A_eff, int32_t* info) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (!mask || !values || !A_eff) return fail(HOMMX_EINVAL, "null mask / values / A_eff");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  const int d = p->desc.dim, t = p->t;
+  unsigned char* d_mask = nullptr;
+  double *d_values = nullptr, *d_M = nullptr, *d_out = nullptr;
+  int32_t* d_info = nullptr;
+  auto cleanup = [&]() {
+    if (d_mask) hipFree(d_mask);
+    if (d_values) hipFree(d_values);
+    if (d_M) hipFree(d_M);
+    if (d_out) hipFree(d_out);
+    if (d_info) hipFree(d_info);
+  };
+#define HIP_TRY_C(expr)                                                                             \
+  do {                                                                                              \
+    hipError_t e__ = (expr);                                                                        \
+    if (e__ != hipSuccess) {                                                                        \
+      cleanup();                                                                                    \
+      return fail(e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP, "%s failed: %s", #expr,   \
+                  hipGetErrorString(e__));                                                          \
+    }                                                                                               \
+  } while (0)
+  HIP_TRY_C(hipMalloc(&d_mask, p->n_el));
+  HIP_TRY_C(hipMalloc(&d_values, sizeof(double) * n_cells * 2 * p->n_comp));
+  HIP_TRY_C(hipMalloc(&d_out, sizeof(double) * n_cells * t * t));
+  HIP_TRY_C(hipMalloc(&d_info, sizeof(int32_t) * n_cells));
+  HIP_TRY_C(hipMemcpy(d_mask, mask, p->n_el, hipMemcpyHostToDevice));
+  HIP_TRY_C(hipMemcpy(d_values, values, sizeof(double) * n_cells * 2 * p->n_comp, hipMemcpyHostToDevice));
+  if (M) {
+    HIP_TRY_C(hipMalloc(&d_M, sizeof(double) * n_cells * d * d));
+    HIP_TRY_C(hipMemcpy(d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
+  }
+  int rc = hommx_solve_batch_two_phase_device(p, n_cells, d_mask, d_values, d_M, d_out, d_info, nullptr);
+  if (rc != HOMMX_OK) {
+    cleanup();
+    return rc;
+  }
+  HIP_TRY_C(hipDeviceSynchronize());
+  HIP_TRY_C(hipMemcpy(A_eff, d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
+  if (info) HIP_TRY_C(hipMemcpy(info, d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
+#undef HIP_TRY_C
+  cleanup();
   return HOMMX_OK;
 }
 

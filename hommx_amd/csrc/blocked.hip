@@ -631,6 +631,28 @@ __global__ __launch_bounds__(64) void k_leaf_inverse(double* __restrict__ S, int
   if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
 }
 
+// two-phase media: expand (mask, per-cell phase values) into the element stream the assembly reads
+__global__ void k_expand_two_phase(const unsigned char* __restrict__ mask, const double* __restrict__ values,
+                                   double* __restrict__ coef, long long n_el, int n_comp, long long ncells) {
+  const long long per = n_el * n_comp;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * per) return;
+  const long long cell = idx / per;
+  const long long rem = idx % per;
+  const long long el = rem / n_comp;
+  const int comp = (int)(rem % n_comp);
+  coef[idx] = values[(cell * 2 + (mask[el] ? 1 : 0)) * n_comp + comp];
+}
+
+hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_values, double* d_coef, long long n_el,
+                                   int n_comp, long long ncells, hipStream_t stream) {
+  const long long work = ncells * n_el * n_comp;
+  if (work <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_expand_two_phase, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, d_mask, d_values, d_coef,
+                     n_el, n_comp, ncells);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------

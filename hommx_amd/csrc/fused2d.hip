@@ -75,7 +75,7 @@ struct alignas(16) Lds {
 template <int NB>
 __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fused(
     const double* __restrict__ coef, const double* __restrict__ Mmat, double* __restrict__ out,
-    int32_t* __restrict__ info, int n, long long ncells) {
+    int32_t* __restrict__ info, int n, long long ncells, const unsigned char* __restrict__ mask) {
   constexpr int RPL = Cfg<NB>::RPL, CG = Cfg<NB>::CG, NT = Cfg<NB>::NT, KK = Cfg<NB>::KK;
   __shared__ Lds<NB> L;
 
@@ -118,14 +118,27 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   const double ga = uniform_f64(0.5 * (m00 * m01 + m10 * m11));
   const double ab = uniform_f64(al - 2.0 * ga + be);
 
-  const double* cc = coef + cell * (2ll * n * n);
+  // Coefficient source: the element stream coef[cell][2 n^2], or -- two-phase media -- a phase mask shared by all
+  // cells (mask[2 n^2], one byte per element) and the two phase values of this cell, coef[cell][2] = (phase 0, phase 1).
+  const double* cc = mask ? coef + cell * 2 : coef + cell * (2ll * n * n);
+  double ph0 = 0.0, ph1 = 0.0;
+  if (mask) {
+    ph0 = cc[0];
+    ph1 = cc[1];
+  }
 
   auto load_row = [&](int jc) {
     CoefRow r;
     r.a0 = 0.0; r.a1 = 0.0;
     if (valid) {
-      const double2 v = *reinterpret_cast<const double2*>(cc + 2 * (jc * n + c));
-      r.a0 = v.x; r.a1 = v.y;
+      if (mask) {
+        const uchar2 mk = *reinterpret_cast<const uchar2*>(mask + 2 * (jc * n + c));
+        r.a0 = mk.x ? ph1 : ph0;
+        r.a1 = mk.y ? ph1 : ph0;
+      } else {
+        const double2 v = *reinterpret_cast<const double2*>(cc + 2 * (jc * n + c));
+        r.a0 = v.x; r.a1 = v.y;
+      }
     }
     r.a0m = __shfl(r.a0, lb + cm, 64);
     r.a1m = __shfl(r.a1, lb + cm, 64);
@@ -564,13 +577,13 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 
 // ---- launch ---------------------------------------------------------------------------------------
 hipError_t launch_poisson2d_fused(const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
-                                  int n, long long ncells, hipStream_t stream) {
+                                  int n, long long ncells, hipStream_t stream, const unsigned char* d_mask) {
   if (ncells <= 0) return hipSuccess;
   dim3 grid((unsigned)ncells), block(64);
   if (n <= 16)
-    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells);
+    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, d_mask);
   else
-    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells);
+    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, d_mask);
   return hipGetLastError();
 }
 

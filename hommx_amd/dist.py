@@ -58,6 +58,8 @@ def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, devi
     if e > b:
         local[: e - b] = plan.solve(coef[b:e], None if M is None else M[b:e])
     tl = torch.from_numpy(local)
+    if device is None and dist.get_backend(group) == "nccl":  # RCCL moves device memory only
+        device = torch.device("cuda", getattr(plan, "device", torch.cuda.current_device()))
     if device is not None:
         tl = tl.to(device)
     full = all_gather_field(tl, world * per, group)

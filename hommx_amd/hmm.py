@@ -90,6 +90,39 @@ class Lame:
         self.lam, self.mu = lam, mu
 
 
+class TwoPhase:
+    """Two-phase coefficient  A(x, y) = inside(x) if indicator(y) else outside(x)  -- the shape of every coefficient in the
+    reference's examples (laminate.py:101-102, inclusion.py:107-118, rotated_fibers.py:23-38: ``ufl.conditional`` of the
+    fast variable between two values).  Passing one as ``A`` lets the solver classes sample on the DEVICE: the phase mask is
+    evaluated once on the micro mesh (element barycentres: UFL estimates degree 0 for a conditional, i.e. the centroid rule)
+    and two values per macro cell are sent instead of n_el samples (``hommx_solve_batch_two_phase``).
+
+    ``indicator(y)``: y[dim, npts] -> bool[npts];  ``inside(x)`` / ``outside(x)``: x[3, N_c] -> scalar, [N_c] array, or a
+    ``Lame`` of such (elasticity).  The object is also a plain callable ``A(x, y)``, so every generic path accepts it.
+    """
+
+    def __init__(self, indicator, inside, outside):
+        self.indicator, self.inside, self.outside = indicator, inside, outside
+
+    @staticmethod
+    def _pair(v, n):
+        if isinstance(v, Lame):
+            return np.stack([np.broadcast_to(np.asarray(v.lam, float), (n,)), np.broadcast_to(np.asarray(v.mu, float), (n,))], axis=-1)
+        return np.broadcast_to(np.asarray(v, float), (n,))
+
+    def phase_values(self, c: np.ndarray) -> np.ndarray:
+        """[N_c, 2(, 2)]: (outside, inside) at the macro cell midpoints c[N_c, 3]."""
+        n = c.shape[0]
+        return np.stack([self._pair(self.outside(c.T), n), self._pair(self.inside(c.T), n)], axis=1)
+
+    def __call__(self, x, y):
+        m = np.asarray(self.indicator(y), dtype=bool)
+        vin, vout = self.inside(x), self.outside(x)
+        if isinstance(vin, Lame):
+            return Lame(np.where(m, vin.lam, vout.lam), np.where(m, vin.mu, vout.mu))
+        return np.where(m, vin, vout)
+
+
 def isotropic_hooke(lam, mu, dim: int) -> np.ndarray:
     lam, mu = np.asarray(lam, float), np.asarray(mu, float)
     I = np.eye(dim)
@@ -281,6 +314,10 @@ class BaseHMM(ABC):
 
     # -- the hot path (replaces the loop hmm.py:298-332) ---------------------------------------------
     def _effective_tensors(self, cells: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        if isinstance(self._coeff, TwoPhase):
+            res = self._effective_tensors_two_phase(cells)
+            if res is not None:
+                return res
         coef, kind = self._element_means(cells)
         M = self._stratification(cells)
         if self._plan is None or self._plan.kind != kind:
@@ -294,6 +331,27 @@ class BaseHMM(ABC):
             AH = solve_sharded(self._plan, coef, M)
             return AH, np.zeros(len(cells), dtype=np.int32)
         return self._plan.solve(coef, M, return_info=True)
+
+    def _effective_tensors_two_phase(self, cells: np.ndarray):
+        """Device-side sampling of a ``TwoPhase`` coefficient: one mask + two values per macro cell."""
+        kind = "poisson" if self._kind == "poisson" else "elasticity"
+        if self._plan is None or self._plan.kind != kind:
+            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
+        if not hasattr(self._plan, "solve_two_phase"):
+            return None
+        import sys
+
+        dist = sys.modules.get("torch.distributed")
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None  # the sharded path goes through the generic element stream
+        d = self._tdim
+        yb = self._cell_mesh.cell_midpoints()[:, :d].T  # element barycentres
+        mask = np.asarray(self._coeff.indicator(yb), dtype=bool)
+        values = self._coeff.phase_values(self._msh.cell_midpoints()[cells])
+        if (values.ndim == 2) != (kind == "poisson"):
+            raise ValueError("TwoPhase values must be scalars for PoissonHMM and Lame(lam, mu) for LinearElasticityHMM")
+        M = self._stratification(cells)
+        return self._plan.solve_two_phase(mask, values, M, return_info=True)
 
     def _local_stiffness_from_tensors(self, cells: np.ndarray, AH: np.ndarray) -> np.ndarray:
         """S_loc = vol(T)/vol(Y) * (macro gradients) A_H (macro gradients)^T  == hmm.py:361-369."""

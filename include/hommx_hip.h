@@ -85,6 +85,25 @@ int hommx_solve_batch(hommx_plan* plan, int64_t n_cells, const double* coef, con
 int hommx_solve_batch_device(hommx_plan* plan, int64_t n_cells, const double* d_coef, const double* d_M,
                              double* d_A_eff, int32_t* d_info, void* stream);
 
+/*
+ * Two-phase media sampled on the device ("on-device coefficient samplers").  Every BASELINE.json
+ * configuration has a coefficient of the form  A(x, y) = indicator(y) ? a_1(x) : a_0(x)  (laminate.py:101-102,
+ * inclusion.py:107-118, rotated_fibers.py:23-38): the fast variable only selects a phase.  Instead of streaming
+ * n_el samples per macro cell the caller passes the phase mask ONCE and two values per cell:
+ *
+ *   mask    [n_el] uint8            phase of every micro element (element order of the DOLFINx-style mesh)
+ *   values  [n_cells][2][n_comp]    coefficient of phase 0 / phase 1 at the macro cell midpoint c_T
+ *
+ * The fused 2D kernel selects in registers (no coefficient stream at all: 16 bytes per cell instead of 16 KiB); the
+ * blocked family expands into its scratch stream on the device.  Host pointers; same outputs as hommx_solve_batch.
+ */
+int hommx_solve_batch_two_phase(hommx_plan* plan, int64_t n_cells, const uint8_t* mask, const double* values,
+                                const double* M, double* A_eff, int32_t* info);
+
+/* Same with DEVICE pointers, asynchronous on `stream`. */
+int hommx_solve_batch_two_phase_device(hommx_plan* plan, int64_t n_cells, const uint8_t* d_mask, const double* d_values,
+                                       const double* d_M, double* d_A_eff, int32_t* d_info, void* stream);
+
 /* Same as hommx_solve_batch, additionally returning the correctors (host pointers):
  *   correctors [n_cells][t][n^d * bs]  chi_m of the canonical load case m (unit gradient e_m / unit strain E^m) at the
  *                                      periodic unknowns, dof = node * bs + component, node = i + n j [+ n^2 k];
