@@ -365,6 +365,110 @@ __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __re
   }
 }
 
+// Same product for planes of <= 256 nodes and Bp <= 768 (3D, n <= 16), rows staged through LDS: the workgroup reads RG
+// rows of IN at a time, fully coalesced and ONCE (the gather of the 3^(d-1) neighbour nodes then hits LDS, not L1/L2),
+// and the next RG rows are in flight in registers while the current ones are multiplied.
+template <int BSV, int NE>
+__global__ __launch_bounds__(256, 2) void k_right_mult_Et_lds(Geo G, const double* __restrict__ Kst,
+                                                              const double* __restrict__ IN, double* __restrict__ OUT,
+                                                              int nrows, int rowPlane, double alpha, int codeOff,
+                                                              int accumulate, int rowsPerBlock) {
+  constexpr int RG = 4, CPT = 3, LDW = 768, NN = NE / BSV;  // NN neighbour nodes, BSV inputs each
+  __shared__ double buf[2][RG][LDW];
+  const int tid = threadIdx.x, q = tid;
+  const long long cell = blockIdx.z;
+  const int kbeg = blockIdx.y * rowsPerBlock, kend = min(nrows, kbeg + rowsPerBlock);
+  if (kbeg >= kend) return;
+  const int Bp = G.Bp;
+  double e[NN][BSV][BSV];  // [neighbour][input component][output component]
+  int nb[NN];
+#pragma unroll
+  for (int m = 0; m < NN; ++m) {
+    nb[m] = 0;
+#pragma unroll
+    for (int be = 0; be < BSV; ++be)
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) e[m][be][al] = 0.0;
+  }
+  if (q < G.npl) {
+    const int nipc = G.ncode / 3;
+    const int node = q + G.npl * rowPlane;
+#pragma unroll
+    for (int m = 0; m < NN; ++m)
+      if (m < nipc) {
+        nb[m] = plane_neighbour(G, q, m) * BSV;
+#pragma unroll
+        for (int be = 0; be < BSV; ++be)
+#pragma unroll
+          for (int al = 0; al < BSV; ++al)
+            e[m][be][al] = Kst[((cell * G.ncode + m + codeOff) * BSV + al) * BSV * (long long)G.nn + (long long)be * G.nn + node];
+      }
+  }
+  const long long per = (long long)nrows * Bp;
+  const double* in = IN + cell * per;
+  double* out = OUT + cell * per;
+  double g[RG][CPT];
+  auto fetch = [&](int k) {
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) {
+        const int col = tid + 256 * i;
+        g[r][i] = (k + r < kend && col < Bp) ? in[(long long)(k + r) * Bp + col] : 0.0;
+      }
+  };
+  auto stash = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int i = 0; i < CPT; ++i) buf[b][r][tid + 256 * i] = g[r][i];
+  };
+  fetch(kbeg);
+  stash(0);
+  __syncthreads();
+  int cur = 0;
+  for (int k = kbeg; k < kend; k += RG) {
+    const bool more = k + RG < kend;
+    if (more) fetch(k + RG);
+#pragma unroll 1
+    for (int r = 0; r < RG; ++r) {
+      if (k + r >= kend) break;
+      const double* row = &buf[cur][r][0];
+      double acc[BSV];
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) acc[al] = 0.0;
+      double v[BSV], w[BSV];
+#pragma unroll
+      for (int be = 0; be < BSV; ++be) v[be] = row[nb[0] + be];
+#pragma unroll
+      for (int m = 0; m < NN; ++m) {  // one neighbour node ahead in flight; no more (register budget: e[] is 2 NE VGPRs)
+        if (m + 1 < NN) {
+#pragma unroll
+          for (int be = 0; be < BSV; ++be) w[be] = row[nb[m + 1] + be];
+        }
+#pragma unroll
+        for (int be = 0; be < BSV; ++be)
+#pragma unroll
+          for (int al = 0; al < BSV; ++al) acc[al] = fma(v[be], e[m][be][al], acc[al]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int be = 0; be < BSV; ++be) v[be] = w[be];
+      }
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) {
+        const int c = q * BSV + al;
+        if (c < Bp) {
+          double* o = out + (long long)(k + r) * Bp + c;
+          *o = accumulate ? *o + alpha * acc[al] : alpha * acc[al];
+        }
+      }
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // OUT[r][c] = alpha * sum_k E[r][k] X[k][c]   (Bp x Bp).  One workgroup per node q (its bs rows r = q bs + al):
 // the bs x NE entries of E and the NE row indices are staged in LDS once; every thread then walks its columns c,
 // loading each X[k][c] once for the bs output rows.
@@ -411,6 +515,97 @@ __global__ __launch_bounds__(256) void k_left_mult_E(Geo G, const double* __rest
 #pragma unroll
     for (int al = 0; al < BSV; ++al) out[(long long)(q * BSV + al) * G.Bp + c] = alpha * acc[al];
   }
+}
+
+// Same product for 3D planes with n <= 16: one workgroup per MESH ROW of the plane (n nodes, n BSV output rows) and
+// 32-column chunks.  The 3 n BSV input rows the strip depends on (mesh rows j-1, j, j+1) are staged through LDS once
+// per chunk -- 3x read amplification instead of the 9x of the node-per-workgroup kernel -- with the next chunk in flight
+// in registers; thread (i, cp) owns node i of the strip and columns 2 cp, 2 cp + 1.
+template <int BSV>
+__global__ __launch_bounds__(256) void k_left_mult_E_strip(Geo G, const double* __restrict__ Kst,
+                                                           const double* __restrict__ X, double* __restrict__ OUT,
+                                                           int rowPlane, double alpha) {
+  constexpr int CW = 32, NN = 9, SLMAX = 16 * BSV, LPT = (SLMAX * CW + 255) / 256;  // loads per thread per segment
+  constexpr int NEB = NN * BSV * BSV;
+  __shared__ double xs[3][SLMAX][CW];
+  __shared__ double es[16][NEB];  // E of the strip's nodes: [node][neighbour][be][al]  (read as 16-lane broadcasts)
+  const int tid = threadIdx.x, i = tid >> 4, cp = tid & 15;
+  const int n = G.n, jrow = blockIdx.x, SL = n * BSV, Bp = G.Bp;
+  const long long cell = blockIdx.z;
+  const long long per = (long long)Bp * Bp;
+  const double* x = X + cell * per;
+  double* out = OUT + cell * per;
+  const bool active = i < n;
+  for (int el = tid; el < 16 * NEB; el += 256) {
+    const int nd = el / NEB, rem = el % NEB, m = rem / (BSV * BSV), be = (rem / BSV) % BSV, al = rem % BSV;
+    double v = 0.0;
+    if (nd < n) {
+      const int node = nd + n * jrow + G.npl * rowPlane;
+      v = Kst[((cell * G.ncode + m) * BSV + al) * BSV * (long long)G.nn + (long long)be * G.nn + node];
+    }
+    es[nd][rem] = v;
+  }
+  int lrow[NN];  // LDS row of the neighbour's first component: (oy + 1) * SLMAX + i' * BSV
+#pragma unroll
+  for (int m = 0; m < NN; ++m) {
+    const int ox = m % 3 - 1, oy = m / 3 - 1;
+    lrow[m] = active ? (oy + 1) * SLMAX + ((i + ox + n) % n) * BSV : 0;
+  }
+  int grow[3];  // first global row of the three input segments
+#pragma unroll
+  for (int sgm = 0; sgm < 3; ++sgm) grow[sgm] = ((jrow + sgm - 1 + n) % n) * SL;
+  double g[3][LPT];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+      for (int m = 0; m < LPT; ++m) {
+        const int el = tid + 256 * m, r = el >> 5, col = el & 31;
+        g[sgm][m] = (r < SL) ? x[(long long)(grow[sgm] + r) * Bp + c0 + col] : 0.0;
+      }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+      for (int m = 0; m < LPT; ++m) {
+        const int el = tid + 256 * m, r = el >> 5, col = el & 31;
+        if (r < SLMAX) xs[sgm][r][col] = g[sgm][m];
+      }
+  };
+  fetch(0);
+  const double* ei = &es[i][0];
+  for (int c0 = 0; c0 < Bp; c0 += CW) {
+    stash();
+    __syncthreads();
+    if (c0 + CW < Bp) fetch(c0 + CW);
+    double acc[BSV][2];
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) acc[al][0] = acc[al][1] = 0.0;
+    const double* base = &xs[0][0][0] + 2 * cp;
+#pragma unroll
+    for (int m = 0; m < NN; ++m) {
+#pragma unroll
+      for (int be = 0; be < BSV; ++be) {
+        const double2 v = *reinterpret_cast<const double2*>(base + (lrow[m] + be) * CW);
+#pragma unroll
+        for (int al = 0; al < BSV; ++al) {
+          const double ev = ei[(m * BSV + be) * BSV + al];
+          acc[al][0] = fma(ev, v.x, acc[al][0]);
+          acc[al][1] = fma(ev, v.y, acc[al][1]);
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int al = 0; al < BSV; ++al)
+        *reinterpret_cast<double2*>(out + (long long)((i + n * jrow) * BSV + al) * Bp + c0 + 2 * cp) =
+            double2{alpha * acc[al][0], alpha * acc[al][1]};
+    }
+    __syncthreads();
+  }
+  if (jrow == 0)  // padding rows b .. Bp-1 of the output are zero
+    for (long long idx = (long long)G.b * Bp + tid; idx < per; idx += 256) out[idx] = 0.0;
 }
 
 // R[m][c] (+)= B[m][(c in plane)]  (16 x Bp load rows)
@@ -494,7 +689,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
                                               long long sA, const double* __restrict__ B, int ldb, long long sB,
                                               double beta, double* __restrict__ C, int ldc, long long sC,
-                                              int lowerOnly) {
+                                              int lowerOnly, double* __restrict__ Ct) {
   if (lowerOnly && blockIdx.x > blockIdx.y) return;  // symmetric result: tiles above the diagonal are mirrored later
   __shared__ double As[16 * GP];
   __shared__ double Bs[16 * GP];
@@ -504,6 +699,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha,
   A += cell * sA;
   B += cell * sB;
   C += cell * sC;
+  if (Ct) Ct += cell * sC;
   const int wi0 = 32 * (w >> 1), wj0 = 32 * (w & 1);
   const int l15 = l & 15, l4 = l >> 4;
   d4 acc[2][2];
@@ -584,6 +780,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha,
           double v = alpha * acc[a][b][r];
           if (beta != 0.0) v += beta * *p;
           *p = v;
+          if (Ct) Ct[(long long)col * ldc + row] = v;  // mirrored copy (same leading dimension and batch stride as C)
         }
       }
 }
@@ -813,6 +1010,134 @@ static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// large-tile variant: 128x128 per 256-thread workgroup (64x64 = 4x4 MFMA tiles per wave), K staged 16 at a time
+// with the next stage prefetched into registers while the current one is multiplied.  Halves the L2 -> LDS traffic
+// per flop of the 64x64 kernel (16 vs 8 flop/B), which is what bounds that kernel once the panels of the ~14 cells
+// in flight no longer fit the 4 MB L2 of an XCD.  The grid is one-dimensional and XCD-aware: workgroup g runs on XCD
+// g % 8 (round-robin dispatch), so cell = 8 * (slot / T) + g % 8 keeps ALL tiles of one cell on one XCD's L2.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GP2 = 144;  // 288 dwords == 32 mod 64, as GP
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double alpha, const double* __restrict__ A,
+                                                    int lda, long long sA, const double* __restrict__ B, int ldb,
+                                                    long long sB, double beta, double* __restrict__ C, int ldc,
+                                                    long long sC, int lowerOnly, int nc, int tilesX, int tilesPerCell,
+                                                    double* __restrict__ Ct) {
+  __shared__ double As[16 * GP2];
+  __shared__ double Bs[16 * GP2];
+  const int g = blockIdx.x, slot = g >> 3;
+  const long long cell = 8ll * (slot / tilesPerCell) + (g & 7);
+  if (cell >= nc) return;
+  const int tile = slot % tilesPerCell;
+  int ty, tx;
+  if (lowerOnly) {  // tiles of the lower triangle, row by row
+    ty = 0;
+    while ((ty + 1) * (ty + 2) / 2 <= tile) ++ty;
+    tx = tile - ty * (ty + 1) / 2;
+  } else {
+    ty = tile / tilesX;
+    tx = tile % tilesX;
+  }
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int m0 = ty * 128, n0 = tx * 128;
+  A += cell * sA;
+  B += cell * sB;
+  C += cell * sC;
+  if (Ct) Ct += cell * sC;
+  const int wi0 = 64 * (w >> 1), wj0 = 64 * (w & 1);
+  const int l15 = l & 15, l4 = l >> 4;
+  d4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // staging maps.  "row-major along k" operand (A not transposed / B transposed): thread -> row t >> 1, 8 k's;
+  // "k-major" operand (A transposed / B not transposed): thread -> k = t >> 4, 8 consecutive rows.
+  const int rk_row = tid >> 1, rk_k = (tid & 1) * 8;
+  const int km_k = tid >> 4, km_row = (tid & 15) * 8;
+  double pa[8], pb[8];
+  auto fetch = [&](int k0) {
+    const double* p;
+    bool ok;
+    if (!TA) { ok = m0 + rk_row < M; p = A + (long long)(m0 + rk_row) * lda + k0 + rk_k; }
+    else     { ok = m0 + km_row < M; p = A + (long long)(k0 + km_k) * lda + m0 + km_row; }
+#pragma unroll
+    for (int x = 0; x < 8; x += 2) {
+      double2 v = double2{0.0, 0.0};
+      if (ok) v = *reinterpret_cast<const double2*>(p + x);
+      pa[x] = v.x; pa[x + 1] = v.y;
+    }
+    if (TB) { ok = n0 + rk_row < N; p = B + (long long)(n0 + rk_row) * ldb + k0 + rk_k; }
+    else    { ok = n0 + km_row < N; p = B + (long long)(k0 + km_k) * ldb + n0 + km_row; }
+#pragma unroll
+    for (int x = 0; x < 8; x += 2) {
+      double2 v = double2{0.0, 0.0};
+      if (ok) v = *reinterpret_cast<const double2*>(p + x);
+      pb[x] = v.x; pb[x + 1] = v.y;
+    }
+  };
+  auto stash = [&]() {
+    if (!TA) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) As[(rk_k + x) * GP2 + rk_row] = pa[x];
+    } else {
+#pragma unroll
+      for (int x = 0; x < 8; x += 2) *reinterpret_cast<double2*>(&As[km_k * GP2 + km_row + x]) = double2{pa[x], pa[x + 1]};
+    }
+    if (TB) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) Bs[(rk_k + x) * GP2 + rk_row] = pb[x];
+    } else {
+#pragma unroll
+      for (int x = 0; x < 8; x += 2) *reinterpret_cast<double2*>(&Bs[km_k * GP2 + km_row + x]) = double2{pb[x], pb[x + 1]};
+    }
+  };
+
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const bool more = k0 + 16 < K;
+    if (more) fetch(k0 + 16);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      double af[4], bf[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = As[(4 * ks + l4) * GP2 + wi0 + 16 * a + l15];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = Bs[(4 * ks + l4) * GP2 + wj0 + 16 * b + l15];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      stash();
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
+        if (row < M && col < N) {
+          double* p = C + (long long)row * ldc + col;
+          double v = alpha * acc[a][b][r];
+          if (beta != 0.0) v += beta * *p;
+          *p = v;
+          if (Ct) Ct[(long long)col * ldc + row] = v;  // mirrored copy (same leading dimension and batch stride as C)
+        }
+      }
+}
+
 namespace {
 struct Ctx {
   BlockedWorkspace* ws;
@@ -825,16 +1150,34 @@ struct Ctx {
 inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + bs - 1) / bs); }
 
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
-          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0) {
+          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0,
+          double* Ct = nullptr) {
+  static const int min128 = [] {  // dev knob: smallest M, N routed to the 128x128 kernel (tests lower it to cover partial tiles)
+    const char* e = getenv("HOMMX_GEMM128_MIN");
+    return e ? atoi(e) : 256;
+  }();
+  if (M >= min128 && N >= min128) {
+    const int tx = (N + 127) / 128, ty = (M + 127) / 128;
+    const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;
+    const long long groups = (c.nc + 7) / 8;
+    dim3 grid((unsigned)(groups * 8 * T)), block(256);
+#define HOMMX_G128(TA_, TB_) hipLaunchKernelGGL((k_gemm128<TA_, TB_>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct)
+    if (!ta && !tb) HOMMX_G128(false, false);
+    else if (!ta && tb) HOMMX_G128(false, true);
+    else if (ta && !tb) HOMMX_G128(true, false);
+    else HOMMX_G128(true, true);
+#undef HOMMX_G128
+    return;
+  }
   dim3 grid((N + 63) / 64, (M + 63) / 64, (unsigned)c.nc), block(256);
   if (!ta && !tb)
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
   else if (!ta && tb)
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
   else if (ta && !tb)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
   else
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly);
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
 }
 
 void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha,
@@ -845,6 +1188,16 @@ void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int r
   dim3 grid((nodes + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
   const int codeOff = (olast + 1) * (G.ncode / 3);
+  if (G.dim == 3 && G.npl <= 256 && G.Bp <= 768 && !getenv("HOMMX_SPARSE_V1")) {  // LDS-staged rows
+    int rpb = 64;
+    while (rpb > 8 && (long long)((nrows + rpb - 1) / rpb) * c.nc < 2048) rpb /= 2;  // keep >= ~4 workgroups per slot
+    dim3 g2(1, (nrows + rpb - 1) / rpb, (unsigned)c.nc);
+    if (ne == 9)
+      hipLaunchKernelGGL((k_right_mult_Et_lds<1, 9>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
+    else
+      hipLaunchKernelGGL((k_right_mult_Et_lds<3, 27>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
+    return;
+  }
 #define HOMMX_RM(BSV, NE) hipLaunchKernelGGL((k_right_mult_Et<BSV, NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate)
   if (ne == 3) HOMMX_RM(1, 3);
   else if (ne == 6) HOMMX_RM(2, 6);
@@ -857,6 +1210,12 @@ void left_mult_E(const Ctx& c, const double* X, double* OUT, int rowPlane, doubl
   const Geo& G = c.ws->G;
   dim3 grid((G.Bp + G.bs - 1) / G.bs, 1, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
+  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !getenv("HOMMX_SPARSE_V1")) {  // strip kernel
+    dim3 g2((unsigned)G.n, 1, (unsigned)c.nc);
+    if (G.bs == 1) hipLaunchKernelGGL((k_left_mult_E_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha);
+    else hipLaunchKernelGGL((k_left_mult_E_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha);
+    return;
+  }
 #define HOMMX_LM(BSV, NE) hipLaunchKernelGGL((k_left_mult_E<BSV, NE>), grid, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha)
   if (ne == 3) HOMMX_LM(1, 3);
   else if (ne == 6) HOMMX_LM(2, 6);
@@ -891,10 +1250,8 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
   gemm(c, false, true, s2, s2, s1, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A22, ld, sS, 1);  // A22 <- A22 - Xm A21^T (symmetric: lower tiles;
                                                                                           //  the recursion below never reads above the diagonal tiles)
   invert(c, S, off + s1, s2, tmp + (long long)s1 * s2);                        // A22 <- (Schur)^-1
-  gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sS, 0.0, A21, ld, sS);  // A21 <- -T^-1 Xm
+  gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sS, 0.0, A21, ld, sS, 0, A12);  // A21 <- -T^-1 Xm, A12 <- A21^T
   gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A11, ld, sS);   // A11 <- A11^-1 - Xm^T A21
-  hipLaunchKernelGGL(k_transpose, dim3(nblk(c.nc * (long long)s1 * s2)), dim3(256), 0, c.st, s1, s2, A21, ld, sS, A12, ld,
-                     sS, c.nc);                                                  // A12 <- A21^T
 }
 }  // namespace
 

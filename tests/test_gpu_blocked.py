@@ -194,3 +194,46 @@ def test_bitwise_reproducible(rng):
     coef3 = np.stack([rng.uniform(0.5, 2.0, (4, 6 * 4**3)), rng.uniform(0.1, 10.0, (4, 6 * 4**3))], axis=-1)
     q = plan(3, 4, "elasticity")
     assert np.array_equal(q.solve(coef3), q.solve(coef3))
+
+
+_G128_CASES = (("elasticity", 3, 5), ("poisson", 2, 12), ("elasticity", 2, 9))
+
+
+def _g128_inputs(p, dim, seed):
+    rng = np.random.default_rng(seed)
+    shape = (11, p.n_el) + ((p.n_comp,) if p.n_comp > 1 else ())
+    return rng.uniform(0.3, 3.0, size=shape), np.eye(dim)[None] + 0.2 * rng.standard_normal((11, dim, dim))
+
+
+def test_large_tile_gemm_on_partial_tiles(tmp_path):
+    """Route every GEMM of small problems (Bp = 96 / 160: partial 128-tiles, lower-only tiles, all transposes) through the
+    128x128 kernel -- which production sizes reach only for Bp >= 256 -- and compare with the oracle and the default route.
+    The knob is read once per process, hence the child process."""
+    import subprocess, sys, textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        from oracle import hommx_oracle as O
+        from test_gpu_blocked import _G128_CASES, _g128_inputs
+        for kind, dim, n in _G128_CASES:
+            p = MicroCellPlan(dim, n, kind, flags=1)
+            coef, M = _g128_inputs(p, dim, 5)
+            A, info = p.solve(coef, M, return_info=True)
+            assert not info.any()
+            ref = O.effective_tensor_batch(kind, dim, n, coef[:3], M[:3])
+            err = np.abs(A[:3] - ref).max() / np.abs(ref).max()
+            assert err < 1e-11, (kind, dim, n, err)
+            np.save({str(tmp_path)!r} + f"/{{kind}}_{{dim}}_{{n}}.npy", A)
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HOMMX_GEMM128_MIN="32"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    for kind, dim, n in _G128_CASES:
+        p = plan(dim, n, kind, flags=1)
+        coef, M = _g128_inputs(p, dim, 5)
+        B = np.load(tmp_path / f"{kind}_{dim}_{n}.npy")
+        assert np.abs(p.solve(coef, M) - B).max() <= 1e-12 * np.abs(B).max()
