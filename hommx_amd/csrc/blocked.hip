@@ -373,8 +373,9 @@ __global__ __launch_bounds__(256, 2) void k_right_mult_Et_lds(Geo G, const doubl
                                                               const double* __restrict__ IN, double* __restrict__ OUT,
                                                               int nrows, int rowPlane, double alpha, int codeOff,
                                                               int accumulate, int rowsPerBlock) {
-  constexpr int RG = 4, CPT = 3, LDW = 768, NN = NE / BSV;  // NN neighbour nodes, BSV inputs each
-  __shared__ double buf[2][RG][LDW];
+  constexpr int RG = 4, CPT2 = 2, LDW = 768, NN = NE / BSV;  // NN neighbour nodes, BSV inputs each
+  __shared__ alignas(16) double buf[RG][LDW];
+  __shared__ alignas(16) double obuf[RG][LDW];
   const int tid = threadIdx.x, q = tid;
   const long long cell = blockIdx.z;
   const int kbeg = blockIdx.y * rowsPerBlock, kend = min(nrows, kbeg + rowsPerBlock);
@@ -407,33 +408,37 @@ __global__ __launch_bounds__(256, 2) void k_right_mult_Et_lds(Geo G, const doubl
   const long long per = (long long)nrows * Bp;
   const double* in = IN + cell * per;
   double* out = OUT + cell * per;
-  double g[RG][CPT];
+  const int Bp2 = Bp >> 1;  // rows move as double2 (Bp is a multiple of 32): lane-contiguous 16 B accesses
+  double2 g[RG][CPT2];
   auto fetch = [&](int k) {
 #pragma unroll
     for (int r = 0; r < RG; ++r)
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) {
-        const int col = tid + 256 * i;
-        g[r][i] = (k + r < kend && col < Bp) ? in[(long long)(k + r) * Bp + col] : 0.0;
+      for (int i = 0; i < CPT2; ++i) {
+        const int c2 = tid + 256 * i;
+        g[r][i] = (k + r < kend && c2 < Bp2) ? reinterpret_cast<const double2*>(in + (long long)(k + r) * Bp)[c2]
+                                            : double2{0.0, 0.0};
       }
   };
-  auto stash = [&](int b) {
+  auto stash = [&]() {
 #pragma unroll
     for (int r = 0; r < RG; ++r)
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) buf[b][r][tid + 256 * i] = g[r][i];
+      for (int i = 0; i < CPT2; ++i) {
+        const int c2 = tid + 256 * i;
+        if (c2 < LDW / 2) reinterpret_cast<double2*>(&buf[r][0])[c2] = g[r][i];
+      }
   };
   fetch(kbeg);
-  stash(0);
+  stash();
   __syncthreads();
-  int cur = 0;
   for (int k = kbeg; k < kend; k += RG) {
     const bool more = k + RG < kend;
     if (more) fetch(k + RG);
 #pragma unroll 1
     for (int r = 0; r < RG; ++r) {
       if (k + r >= kend) break;
-      const double* row = &buf[cur][r][0];
+      const double* row = &buf[r][0];
       double acc[BSV];
 #pragma unroll
       for (int al = 0; al < BSV; ++al) acc[al] = 0.0;
@@ -457,15 +462,28 @@ __global__ __launch_bounds__(256, 2) void k_right_mult_Et_lds(Geo G, const doubl
 #pragma unroll
       for (int al = 0; al < BSV; ++al) {
         const int c = q * BSV + al;
-        if (c < Bp) {
-          double* o = out + (long long)(k + r) * Bp + c;
-          *o = accumulate ? *o + alpha * acc[al] : alpha * acc[al];
-        }
+        if (c < LDW) obuf[r][c] = alpha * acc[al];
       }
     }
-    if (more) stash(cur ^ 1);
+    __syncthreads();  // obuf complete, buf consumed
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int i = 0; i < CPT2; ++i) {
+        const int c2 = tid + 256 * i;
+        if (k + r < kend && c2 < Bp2) {
+          double2* o = reinterpret_cast<double2*>(out + (long long)(k + r) * Bp) + c2;
+          double2 t = reinterpret_cast<const double2*>(&obuf[r][0])[c2];
+          if (accumulate) {
+            const double2 old = *o;
+            t.x += old.x;
+            t.y += old.y;
+          }
+          *o = t;
+        }
+      }
+    if (more) stash();
     __syncthreads();
-    cur ^= 1;
   }
 }
 
@@ -522,7 +540,7 @@ __global__ __launch_bounds__(256) void k_left_mult_E(Geo G, const double* __rest
 // per chunk -- 3x read amplification instead of the 9x of the node-per-workgroup kernel -- with the next chunk in flight
 // in registers; thread (i, cp) owns node i of the strip and columns 2 cp, 2 cp + 1.
 template <int BSV>
-__global__ __launch_bounds__(256) void k_left_mult_E_strip(Geo G, const double* __restrict__ Kst,
+__global__ __launch_bounds__(256, 3) void k_left_mult_E_strip(Geo G, const double* __restrict__ Kst,
                                                            const double* __restrict__ X, double* __restrict__ OUT,
                                                            int rowPlane, double alpha) {
   constexpr int CW = 32, NN = 9, SLMAX = 16 * BSV, LPT = (SLMAX * CW + 255) / 256;  // loads per thread per segment
@@ -574,7 +592,6 @@ __global__ __launch_bounds__(256) void k_left_mult_E_strip(Geo G, const double* 
       }
   };
   fetch(0);
-  const double* ei = &es[i][0];
   for (int c0 = 0; c0 < Bp; c0 += CW) {
     stash();
     __syncthreads();
@@ -582,6 +599,9 @@ __global__ __launch_bounds__(256) void k_left_mult_E_strip(Geo G, const double* 
     double acc[BSV][2];
 #pragma unroll
     for (int al = 0; al < BSV; ++al) acc[al][0] = acc[al][1] = 0.0;
+    int eo = i * NEB;
+    asm volatile("" : "+v"(eo));  // keep the E reads in the loop: hoisted they cost 2 NEB VGPRs and a workgroup per CU
+    const double* ei = &es[0][0] + eo;
     const double* base = &xs[0][0][0] + 2 * cp;
 #pragma unroll
     for (int m = 0; m < NN; ++m) {
@@ -595,6 +615,12 @@ __global__ __launch_bounds__(256) void k_left_mult_E_strip(Geo G, const double* 
           acc[al][1] = fma(ev, v.y, acc[al][1]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) {
+      acc[al][0] = pin_here(acc[al][0]);
+      acc[al][1] = pin_here(acc[al][1]);
     }
     if (active) {
 #pragma unroll
@@ -606,6 +632,111 @@ __global__ __launch_bounds__(256) void k_left_mult_E_strip(Geo G, const double* 
   }
   if (jrow == 0)  // padding rows b .. Bp-1 of the output are zero
     for (long long idx = (long long)G.b * Bp + tid; idx < per; idx += 256) out[idx] = 0.0;
+}
+
+// OUT = alpha IN E^T in the same strip form (the transposed twin of k_left_mult_E_strip): one workgroup per mesh row of
+// the plane (its n BSV OUTPUT COLUMNS) and block of rows; 32 rows at a time, the 3 n BSV input columns of each go
+// through LDS transposed ([column][row], pitch 34), so the inner loop is the 16 B-read / 16-lane-broadcast loop above.
+// E stays in LDS (re-read per chunk: an empty asm hides the loop invariance) to keep 3 workgroups per CU.
+template <int BSV>
+__global__ __launch_bounds__(256, 3) void k_right_mult_Et_strip(Geo G, const double* __restrict__ Kst,
+                                                                const double* __restrict__ IN, double* __restrict__ OUT,
+                                                                int nrows, int rowPlane, double alpha, int codeOff,
+                                                                int accumulate, int rowsPerBlock) {
+  constexpr int CW = 32, CWP = 34, NN = 9, SLMAX = 16 * BSV, LPT = SLMAX / 8;  // loads per thread per segment
+  constexpr int NEB = NN * BSV * BSV;
+  __shared__ alignas(16) double xs[3][SLMAX][CWP];
+  __shared__ double es[16][NEB];
+  const int tid = threadIdx.x, i = tid >> 4, rp = tid & 15;
+  const int n = G.n, jrow = blockIdx.x, SL = n * BSV, Bp = G.Bp;
+  const long long cell = blockIdx.z;
+  const int kbeg = blockIdx.y * rowsPerBlock, kend = min(nrows, kbeg + rowsPerBlock);
+  if (kbeg >= kend) return;
+  const long long per = (long long)nrows * Bp;
+  const double* in = IN + cell * per;
+  double* out = OUT + cell * per;
+  const bool active = i < n;
+  for (int el = tid; el < 16 * NEB; el += 256) {
+    const int nd = el / NEB, rem = el % NEB, m = rem / (BSV * BSV), be = (rem / BSV) % BSV, al = rem % BSV;
+    double v = 0.0;
+    if (nd < n && m < G.ncode / 3) {
+      const int node = nd + n * jrow + G.npl * rowPlane;
+      v = Kst[((cell * G.ncode + m + codeOff) * BSV + al) * BSV * (long long)G.nn + (long long)be * G.nn + node];
+    }
+    es[nd][rem] = v;
+  }
+  int lrow[NN];
+#pragma unroll
+  for (int m = 0; m < NN; ++m) {
+    const int ox = m % 3 - 1, oy = m / 3 - 1;
+    lrow[m] = (active ? (oy + 1) * SLMAX + ((i + ox + n) % n) * BSV : 0) * CWP + 2 * rp;
+  }
+  int gcol[3];  // first global column of the three input segments
+#pragma unroll
+  for (int sgm = 0; sgm < 3; ++sgm) gcol[sgm] = ((jrow + sgm - 1 + n) % n) * SL;
+  const int fr = tid >> 3, fc = tid & 7;  // staging: row fr of the chunk, columns fc + 8 m
+  double g[3][LPT];
+  auto fetch = [&](int k0) {
+    // unconditional loads (clamped indices): rows >= kend and columns >= SL land in LDS slots no stored output reads
+    const double* src = in + (long long)min(k0 + fr, kend - 1) * Bp;
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+      for (int m = 0; m < LPT; ++m) g[sgm][m] = src[gcol[sgm] + min(fc + 8 * m, SL - 1)];
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+      for (int m = 0; m < LPT; ++m) xs[sgm][fc + 8 * m][fr] = g[sgm][m];
+  };
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += CW) {
+    stash();
+    __syncthreads();
+    if (k0 + CW < kend) fetch(k0 + CW);
+    double acc[BSV][2];
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) acc[al][0] = acc[al][1] = 0.0;
+    int eo = i * NEB;
+    asm volatile("" : "+v"(eo));
+    const double* ei = &es[0][0] + eo;
+    const double* base = &xs[0][0][0];
+#pragma unroll
+    for (int m = 0; m < NN; ++m) {
+#pragma unroll
+      for (int be = 0; be < BSV; ++be) {
+        const double2 v = *reinterpret_cast<const double2*>(base + lrow[m] + be * CWP);
+#pragma unroll
+        for (int al = 0; al < BSV; ++al) {
+          const double ev = ei[(m * BSV + be) * BSV + al];
+          acc[al][0] = fma(ev, v.x, acc[al][0]);
+          acc[al][1] = fma(ev, v.y, acc[al][1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int al = 0; al < BSV; ++al) {  // the products are final here: do not let them sink into the guarded stores
+      acc[al][0] = pin_here(acc[al][0]);
+      acc[al][1] = pin_here(acc[al][1]);
+    }
+    if (active) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = k0 + 2 * rp + h;
+        if (k < kend) {
+          double* o = out + (long long)k * Bp + (i + n * jrow) * BSV;
+#pragma unroll
+          for (int al = 0; al < BSV; ++al) o[al] = accumulate ? o[al] + alpha * acc[al][h] : alpha * acc[al][h];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (jrow == 0 && !accumulate)  // padding columns b .. Bp-1 of the output are zero
+    for (int k = kbeg; k < kend; ++k)
+      for (int cc = G.b + tid; cc < Bp; cc += 256) out[(long long)k * Bp + cc] = 0.0;
 }
 
 // R[m][c] (+)= B[m][(c in plane)]  (16 x Bp load rows)
@@ -1188,6 +1319,16 @@ void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int r
   dim3 grid((nodes + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
   const int codeOff = (olast + 1) * (G.ncode / 3);
+  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !getenv("HOMMX_SPARSE_V1") && !getenv("HOMMX_SPARSE_V2")) {
+    int rpb = 128;
+    while (rpb > 32 && (long long)((nrows + rpb - 1) / rpb) * c.nc * G.n < 4096) rpb /= 2;
+    dim3 g2((unsigned)G.n, (nrows + rpb - 1) / rpb, (unsigned)c.nc);
+    if (G.bs == 1)
+      hipLaunchKernelGGL((k_right_mult_Et_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
+    else
+      hipLaunchKernelGGL((k_right_mult_Et_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
+    return;
+  }
   if (G.dim == 3 && G.npl <= 256 && G.Bp <= 768 && !getenv("HOMMX_SPARSE_V1")) {  // LDS-staged rows
     int rpb = 64;
     while (rpb > 8 && (long long)((nrows + rpb - 1) / rpb) * c.nc < 2048) rpb /= 2;  // keep >= ~4 workgroups per slot
