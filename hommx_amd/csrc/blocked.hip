@@ -365,128 +365,6 @@ __global__ __launch_bounds__(256) void k_right_mult_Et(Geo G, const double* __re
   }
 }
 
-// Same product for planes of <= 256 nodes and Bp <= 768 (3D, n <= 16), rows staged through LDS: the workgroup reads RG
-// rows of IN at a time, fully coalesced and ONCE (the gather of the 3^(d-1) neighbour nodes then hits LDS, not L1/L2),
-// and the next RG rows are in flight in registers while the current ones are multiplied.
-template <int BSV, int NE>
-__global__ __launch_bounds__(256, 2) void k_right_mult_Et_lds(Geo G, const double* __restrict__ Kst,
-                                                              const double* __restrict__ IN, double* __restrict__ OUT,
-                                                              int nrows, int rowPlane, double alpha, int codeOff,
-                                                              int accumulate, int rowsPerBlock) {
-  constexpr int RG = 4, CPT2 = 2, LDW = 768, NN = NE / BSV;  // NN neighbour nodes, BSV inputs each
-  __shared__ alignas(16) double buf[RG][LDW];
-  __shared__ alignas(16) double obuf[RG][LDW];
-  const int tid = threadIdx.x, q = tid;
-  const long long cell = blockIdx.z;
-  const int kbeg = blockIdx.y * rowsPerBlock, kend = min(nrows, kbeg + rowsPerBlock);
-  if (kbeg >= kend) return;
-  const int Bp = G.Bp;
-  double e[NN][BSV][BSV];  // [neighbour][input component][output component]
-  int nb[NN];
-#pragma unroll
-  for (int m = 0; m < NN; ++m) {
-    nb[m] = 0;
-#pragma unroll
-    for (int be = 0; be < BSV; ++be)
-#pragma unroll
-      for (int al = 0; al < BSV; ++al) e[m][be][al] = 0.0;
-  }
-  if (q < G.npl) {
-    const int nipc = G.ncode / 3;
-    const int node = q + G.npl * rowPlane;
-#pragma unroll
-    for (int m = 0; m < NN; ++m)
-      if (m < nipc) {
-        nb[m] = plane_neighbour(G, q, m) * BSV;
-#pragma unroll
-        for (int be = 0; be < BSV; ++be)
-#pragma unroll
-          for (int al = 0; al < BSV; ++al)
-            e[m][be][al] = Kst[((cell * G.ncode + m + codeOff) * BSV + al) * BSV * (long long)G.nn + (long long)be * G.nn + node];
-      }
-  }
-  const long long per = (long long)nrows * Bp;
-  const double* in = IN + cell * per;
-  double* out = OUT + cell * per;
-  const int Bp2 = Bp >> 1;  // rows move as double2 (Bp is a multiple of 32): lane-contiguous 16 B accesses
-  double2 g[RG][CPT2];
-  auto fetch = [&](int k) {
-#pragma unroll
-    for (int r = 0; r < RG; ++r)
-#pragma unroll
-      for (int i = 0; i < CPT2; ++i) {
-        const int c2 = tid + 256 * i;
-        g[r][i] = (k + r < kend && c2 < Bp2) ? reinterpret_cast<const double2*>(in + (long long)(k + r) * Bp)[c2]
-                                            : double2{0.0, 0.0};
-      }
-  };
-  auto stash = [&]() {
-#pragma unroll
-    for (int r = 0; r < RG; ++r)
-#pragma unroll
-      for (int i = 0; i < CPT2; ++i) {
-        const int c2 = tid + 256 * i;
-        if (c2 < LDW / 2) reinterpret_cast<double2*>(&buf[r][0])[c2] = g[r][i];
-      }
-  };
-  fetch(kbeg);
-  stash();
-  __syncthreads();
-  for (int k = kbeg; k < kend; k += RG) {
-    const bool more = k + RG < kend;
-    if (more) fetch(k + RG);
-#pragma unroll 1
-    for (int r = 0; r < RG; ++r) {
-      if (k + r >= kend) break;
-      const double* row = &buf[r][0];
-      double acc[BSV];
-#pragma unroll
-      for (int al = 0; al < BSV; ++al) acc[al] = 0.0;
-      double v[BSV], w[BSV];
-#pragma unroll
-      for (int be = 0; be < BSV; ++be) v[be] = row[nb[0] + be];
-#pragma unroll
-      for (int m = 0; m < NN; ++m) {  // one neighbour node ahead in flight; no more (register budget: e[] is 2 NE VGPRs)
-        if (m + 1 < NN) {
-#pragma unroll
-          for (int be = 0; be < BSV; ++be) w[be] = row[nb[m + 1] + be];
-        }
-#pragma unroll
-        for (int be = 0; be < BSV; ++be)
-#pragma unroll
-          for (int al = 0; al < BSV; ++al) acc[al] = fma(v[be], e[m][be][al], acc[al]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int be = 0; be < BSV; ++be) v[be] = w[be];
-      }
-#pragma unroll
-      for (int al = 0; al < BSV; ++al) {
-        const int c = q * BSV + al;
-        if (c < LDW) obuf[r][c] = alpha * acc[al];
-      }
-    }
-    __syncthreads();  // obuf complete, buf consumed
-#pragma unroll
-    for (int r = 0; r < RG; ++r)
-#pragma unroll
-      for (int i = 0; i < CPT2; ++i) {
-        const int c2 = tid + 256 * i;
-        if (k + r < kend && c2 < Bp2) {
-          double2* o = reinterpret_cast<double2*>(out + (long long)(k + r) * Bp) + c2;
-          double2 t = reinterpret_cast<const double2*>(&obuf[r][0])[c2];
-          if (accumulate) {
-            const double2 old = *o;
-            t.x += old.x;
-            t.y += old.y;
-          }
-          *o = t;
-        }
-      }
-    if (more) stash();
-    __syncthreads();
-  }
-}
-
 // OUT[r][c] = alpha * sum_k E[r][k] X[k][c]   (Bp x Bp).  One workgroup per node q (its bs rows r = q bs + al):
 // the bs x NE entries of E and the NE row indices are staged in LDS once; every thread then walks its columns c,
 // loading each X[k][c] once for the bs output rows.
@@ -639,14 +517,15 @@ __global__ __launch_bounds__(256, 3) void k_left_mult_E_strip(Geo G, const doubl
 // through LDS transposed ([column][row], pitch 34), so the inner loop is the 16 B-read / 16-lane-broadcast loop above.
 // E stays in LDS (re-read per chunk: an empty asm hides the loop invariance) to keep 3 workgroups per CU.
 template <int BSV>
-__global__ __launch_bounds__(256, 3) void k_right_mult_Et_strip(Geo G, const double* __restrict__ Kst,
+__global__ __launch_bounds__(256, 2) void k_right_mult_Et_strip(Geo G, const double* __restrict__ Kst,
                                                                 const double* __restrict__ IN, double* __restrict__ OUT,
                                                                 int nrows, int rowPlane, double alpha, int codeOff,
                                                                 int accumulate, int rowsPerBlock) {
-  constexpr int CW = 32, CWP = 34, NN = 9, SLMAX = 16 * BSV, LPT = SLMAX / 8;  // loads per thread per segment
+  constexpr int CW = 32, CWP = 34, NN = 9, SLMAX = 16 * BSV;
   constexpr int NEB = NN * BSV * BSV;
   __shared__ alignas(16) double xs[3][SLMAX][CWP];
   __shared__ double es[16][NEB];
+  __shared__ double ob[CW][SLMAX + 1];
   const int tid = threadIdx.x, i = tid >> 4, rp = tid & 15;
   const int n = G.n, jrow = blockIdx.x, SL = n * BSV, Bp = G.Bp;
   const long long cell = blockIdx.z;
@@ -674,21 +553,26 @@ __global__ __launch_bounds__(256, 3) void k_right_mult_Et_strip(Geo G, const dou
   int gcol[3];  // first global column of the three input segments
 #pragma unroll
   for (int sgm = 0; sgm < 3; ++sgm) gcol[sgm] = ((jrow + sgm - 1 + n) % n) * SL;
-  const int fr = tid >> 3, fc = tid & 7;  // staging: row fr of the chunk, columns fc + 8 m
-  double g[3][LPT];
+  const int fr = tid >> 4, fc = tid & 15;  // staging: rows fr, fr + 16 of the chunk, columns fc + 16 m (128 B runs)
+  double g[3][2][BSV];
   auto fetch = [&](int k0) {
     // unconditional loads (clamped indices): rows >= kend and columns >= SL land in LDS slots no stored output reads
-    const double* src = in + (long long)min(k0 + fr, kend - 1) * Bp;
 #pragma unroll
-    for (int sgm = 0; sgm < 3; ++sgm)
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const double* src = in + (long long)min(k0 + fr + 16 * p2, kend - 1) * Bp;
 #pragma unroll
-      for (int m = 0; m < LPT; ++m) g[sgm][m] = src[gcol[sgm] + min(fc + 8 * m, SL - 1)];
+      for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+        for (int m = 0; m < BSV; ++m) g[sgm][p2][m] = src[gcol[sgm] + min(fc + 16 * m, SL - 1)];
+    }
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int sgm = 0; sgm < 3; ++sgm)
+    for (int p2 = 0; p2 < 2; ++p2)
 #pragma unroll
-      for (int m = 0; m < LPT; ++m) xs[sgm][fc + 8 * m][fr] = g[sgm][m];
+      for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+        for (int m = 0; m < BSV; ++m) xs[sgm][fc + 16 * m][fr + 16 * p2] = g[sgm][p2][m];
   };
   fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += CW) {
@@ -721,18 +605,25 @@ __global__ __launch_bounds__(256, 3) void k_right_mult_Et_strip(Geo G, const dou
       acc[al][0] = pin_here(acc[al][0]);
       acc[al][1] = pin_here(acc[al][1]);
     }
-    if (active) {
+    // the 32 x SL output tile leaves through LDS so that the stores run along rows (64 B per 8 lanes) as the loads do
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k = k0 + 2 * rp + h;
-        if (k < kend) {
-          double* o = out + (long long)k * Bp + (i + n * jrow) * BSV;
+    for (int al = 0; al < BSV; ++al) {
+      ob[2 * rp][i * BSV + al] = alpha * acc[al][0];
+      ob[2 * rp + 1][i * BSV + al] = alpha * acc[al][1];
+    }
+    __syncthreads();
 #pragma unroll
-          for (int al = 0; al < BSV; ++al) o[al] = accumulate ? o[al] + alpha * acc[al][h] : alpha * acc[al][h];
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const int rr = fr + 16 * p2;
+      if (k0 + rr < kend) {
+        double* o = out + (long long)(k0 + rr) * Bp + jrow * SL;
+#pragma unroll
+        for (int m = 0; m < BSV; ++m) {
+          const int cc = fc + 16 * m;
+          if (cc < SL) o[cc] = accumulate ? o[cc] + ob[rr][cc] : ob[rr][cc];
         }
       }
     }
-    __syncthreads();
   }
   if (jrow == 0 && !accumulate)  // padding columns b .. Bp-1 of the output are zero
     for (int k = kbeg; k < kend; ++k)
@@ -1097,7 +988,13 @@ static long long per_cell_bytes(const Geo& G) {
 
 static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
   const Geo& G = ws->G;
-  double budget_gb = 16.0;
+  // workspace budget: the batch kernels keep gaining up to ~1000 cells in flight (small launches of the recursive
+  // inverse amortise), and the card has 288 GB: take up to 64 GB, never more than half of what is free
+  double budget_gb = 64.0;
+  {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gb = std::min(budget_gb, 0.5e-9 * (double)fr);
+  }
   if (const char* e = getenv("HOMMX_BLOCKED_MEM_GB")) budget_gb = atof(e);
   const long long hist_bytes = 8ll * (G.n - 1) * (2ll * G.Bp * G.Bp + 16ll * G.Bp) + 8ll * 3 * 16 * G.Bp;
   if (correctors) {
@@ -1319,24 +1216,14 @@ void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int r
   dim3 grid((nodes + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
   const int codeOff = (olast + 1) * (G.ncode / 3);
-  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !getenv("HOMMX_SPARSE_V1") && !getenv("HOMMX_SPARSE_V2")) {
-    int rpb = 128;
-    while (rpb > 32 && (long long)((nrows + rpb - 1) / rpb) * c.nc * G.n < 4096) rpb /= 2;
+  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !getenv("HOMMX_SPARSE_V1")) {  // strip kernel (HOMMX_SPARSE_V1: dev knob, generic kernels)
+    int rpb = (nrows + 31) / 32 * 32;  // rows per workgroup: as many as still leave ~4 workgroups per slot
+    while (rpb > 32 && (long long)((nrows + rpb - 1) / rpb) * c.nc * G.n < 4096) rpb = (rpb / 2 + 31) / 32 * 32;
     dim3 g2((unsigned)G.n, (nrows + rpb - 1) / rpb, (unsigned)c.nc);
     if (G.bs == 1)
       hipLaunchKernelGGL((k_right_mult_Et_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
     else
       hipLaunchKernelGGL((k_right_mult_Et_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
-    return;
-  }
-  if (G.dim == 3 && G.npl <= 256 && G.Bp <= 768 && !getenv("HOMMX_SPARSE_V1")) {  // LDS-staged rows
-    int rpb = 64;
-    while (rpb > 8 && (long long)((nrows + rpb - 1) / rpb) * c.nc < 2048) rpb /= 2;  // keep >= ~4 workgroups per slot
-    dim3 g2(1, (nrows + rpb - 1) / rpb, (unsigned)c.nc);
-    if (ne == 9)
-      hipLaunchKernelGGL((k_right_mult_Et_lds<1, 9>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
-    else
-      hipLaunchKernelGGL((k_right_mult_Et_lds<3, 27>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
     return;
   }
 #define HOMMX_RM(BSV, NE) hipLaunchKernelGGL((k_right_mult_Et<BSV, NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate)
@@ -1403,7 +1290,11 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
   const int n = G.n, Bp = G.Bp;
   const long long mat = (long long)Bp * Bp;
   if (d_info) BTRY(hipMemsetAsync(d_info, 0, sizeof(int32_t) * ncells, st));
-  const long long step_cells = d_corr ? std::min(ws->chunk, ws->hchunk) : ws->chunk;
+  long long step_cells = d_corr ? std::min(ws->chunk, ws->hchunk) : ws->chunk;
+  if (step_cells > 0) {  // equal chunks: a short tail chunk would run the small kernels of the inverse underfilled
+    const long long nchunks = (ncells + step_cells - 1) / step_cells;
+    step_cells = (ncells + nchunks - 1) / nchunks;
+  }
   for (long long c0 = 0; c0 < ncells; c0 += step_cells) {
     const long long nc = std::min(step_cells, ncells - c0);
     Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
