@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhommx_hip.so")
+LIB_PATH = os.environ.get("HOMMX_LIB") or os.path.join(_HERE, "libhommx_hip.so")  # HOMMX_LIB: A/B builds (dev)
 
 # every symbol include/hommx_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -54,6 +54,30 @@ class HommxLibraryError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process, one HIP runtime.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so.7``; libhommx_hip.so needs the
+    same SONAME.  Whichever copy is loaded first serves both, and torch cannot find a GPU when that is not its own copy
+    ("No HIP GPUs are available" if libhommx_hip.so was loaded before ``import torch``).  So when torch is installed but not
+    imported yet, its copy is loaded first, by path (no ``import torch``: the product does not depend on it)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:  # pragma: no cover - fall back to the system runtime
+            pass
+
+
 def load():
     """Load libhommx_hip.so (once) and declare the prototypes."""
     global _lib
@@ -64,6 +88,7 @@ def load():
             f"{LIB_PATH} not found: build it with `make -C hommx_amd/csrc` (or __graft_entry__.build()). "
             "hommx_amd has no CPU fallback for the micro-cell solves."
         )
+    _share_hip_runtime_with_torch()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the machine

@@ -235,7 +235,6 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   double g00 = 0.0, g01 = 0.0, g11 = 0.0;  // -G partial sums (every lane group holds a copy)
   int bad = 0, badstep = 0;
   const int kq = (n - 1) >> 2, lq = (n - 1) & 3;  // where column n-1 lives in operand layout
-  const int rotsrc = (l - 16) & 63;
 
   // ---- elimination of node rows 0 .. n-2 ----------------------------------------------------------
   for (int j = 0; j <= n - 2; ++j) {
@@ -335,11 +334,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       vr[0] = fma(q0.x, n0, vr[0]); vr[0] = fma(q0.y, n1, vr[0]);
       vr[1] = fma(q1.x, n0, vr[1]); vr[1] = fma(q1.y, n1, vr[1]);
     }
-#pragma unroll
-    for (int off = NB; off < 64; off <<= 1) {
-      vr[0] += __shfl_xor(vr[0], off, 64);
-      vr[1] += __shfl_xor(vr[1], off, 64);
+    if (NB == 16) {
+      vr[0] = add_xor16(vr[0]);
+      vr[1] = add_xor16(vr[1]);
     }
+    vr[0] = add_xor32(vr[0]);
+    vr[1] = add_xor32(vr[1]);
     g00 = fma(vr[0], rr[0], g00);
     g01 = fma(vr[0], rr[1], g01);
     g11 = fma(vr[1], rr[1], g11);
@@ -376,18 +376,19 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           part[1][t] = fma(v1, wf[t][kk], part[1][t]);
         }
       }
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          part[m][t] += __shfl_xor(part[m][t], 16, 64);
-          part[m][t] += __shfl_xor(part[m][t], 32, 64);
-        }
-      // lane column c = 16*(c>>4) + (l&15): pick tile t = c >> 4
+      // sum over the four 16-lane rows.  NT == 2: lane column c = 16 (row & 1) + (l & 15) wants tile (row & 1); the
+      // transposing butterfly delivers exactly that: swap16 -> [A01, B01, A23, B23], swap32 -> [A, B, A, B].
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const double p0 = part[m][0], p1 = part[m][NT - 1];
-        rl[m] += (NT == 2 && (c & 16)) ? p1 : p0;
+        double sum;
+        if (NT == 2) {
+          double a = part[m][0], b = part[m][NT - 1];
+          swap16(a, b);
+          sum = add_xor32(a + b);
+        } else {
+          sum = add_xor32(add_xor16(part[m][0]));
+        }
+        rl[m] += sum;
       }
     }
 
@@ -405,26 +406,27 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           f0[kk] = L.e0[4 * kk + l4];
           f1[kk] = L.e1[4 * kk + l4];
         }
-        int rot = rotsrc;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const double wrapv = L.vcol[16 * t + l15];
+          // left neighbour of column 4 kk + row: rows 1, 3 take rows 0, 2 of the same register (swap16), row 2 takes
+          // row 1 and row 0 takes row 3 of register kk - 1 (one swap32 serves both, chained through `carry`)
+          double carry = 0.0;
 #pragma unroll
-          for (int k4 = 0; k4 < KK; k4 += 4) {
-            double z[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int kk = k4 + q;
-              const double xk = vt[kk >> 2][t][kk & 3];
-              const double xm = (kk == 0) ? wrapv : vt[(kk > 0 ? kk - 1 : 0) >> 2][t][(kk > 0 ? kk - 1 : 0) & 3];
-              z[q] = __shfl((l4 == 3) ? xm : xk, rot, 64);
+          for (int kk = 0; kk < KK; ++kk) {
+            const double x = vt[kk >> 2][t][kk & 3];
+            double tt = x, uu = x;
+            swap16(tt, uu);  // tt = [x0, x0, x2, x2], uu = [x1, x1, x3, x3]
+            double vv = (kk == 0) ? uu : carry;
+            swap32(vv, uu);  // vv = [., ., x1, x1], uu = [prev x3, prev x3, x3, x3]
+            carry = uu;
+            const double z = (l4 & 1) ? tt : ((l4 == 2) ? vv : ((kk == 0) ? wrapv : uu));
+            wf[t][kk] = fma(z, f1[kk], x * f0[kk]);
+            {  // one register at a time (hoisted, the swap temporaries of all kk spill): the next swap32 waits for this fma
+              int clo = __double2loint(carry);
+              asm volatile("" : "+v"(clo) : "v"(__double2loint(wf[t][kk])));
+              carry = __hiloint2double(__double2hiint(carry), clo);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int kk = k4 + q;
-              wf[t][kk] = fma(z[q], f1[kk], vt[kk >> 2][t][kk & 3] * f0[kk]);
-            }
-            asm volatile("" : "+v"(rot) : "v"(__double2loint(wf[t][k4 + 3])));  // bound the shuffles in flight
           }
         }
       }
@@ -537,11 +539,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
       vr[0] = fma(q0.x, n0, vr[0]); vr[0] = fma(q0.y, n1, vr[0]);
       vr[1] = fma(q1.x, n0, vr[1]); vr[1] = fma(q1.y, n1, vr[1]);
     }
-#pragma unroll
-    for (int off = NB; off < 64; off <<= 1) {
-      vr[0] += __shfl_xor(vr[0], off, 64);
-      vr[1] += __shfl_xor(vr[1], off, 64);
+    if (NB == 16) {
+      vr[0] = add_xor16(vr[0]);
+      vr[1] = add_xor16(vr[1]);
     }
+    vr[0] = add_xor32(vr[0]);
+    vr[1] = add_xor32(vr[1]);
     g00 = fma(vr[0], rl[0], g00);
     g01 = fma(vr[0], rl[1], g01);
     g11 = fma(vr[1], rl[1], g11);

@@ -33,6 +33,34 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
+// gfx950 row swaps on doubles (row r = lanes 16r .. 16r+15; measured with tools/probe_permlane.hip):
+//   swap16(a, b): a' = [a0, b0, a2, b2], b' = [a1, b1, a3, b3]        (v_permlane16_swap_b32 on both dwords)
+//   swap32(a, b): a' = [a0, a1, b0, b1], b' = [a2, a3, b2, b3]        (v_permlane32_swap_b32)
+// VALU-latency cross-row traffic: what the reductions over the four 16-lane rows use instead of ds_bpermute.
+__device__ __forceinline__ void swap16(double& a, double& b) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap32(double& a, double& b) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi[0], (int)lo[0]);
+  b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// v(l) + v(l ^ 32)  resp.  + v(l ^ 16), in every lane
+__device__ __forceinline__ double add_xor32(double v) {
+  double t = v, u = v;
+  swap32(t, u);  // t = [v0, v1, v0, v1], u = [v2, v3, v2, v3]
+  return t + u;
+}
+__device__ __forceinline__ double add_xor16(double v) {
+  double t = v, u = v;
+  swap16(t, u);  // t = [v0, v0, v2, v2], u = [v1, v1, v3, v3]
+  return t + u;
+}
+
 // Empty volatile asm through which a value is threaded: pins the computation of `v` before this program point.
 __device__ __forceinline__ double pin_here(double v) {
   int hi = __double2hiint(v), lo = __double2loint(v);
@@ -43,6 +71,19 @@ __device__ __forceinline__ double pin_here(double v) {
 // WSYNC: barrier among the lanes that share ubuf/wbuf.  With one wave per workgroup __syncthreads()
 // lowers to a wait on the LDS counter; kernels with several independent waves per workgroup pass a
 // wave-local fence instead.
+// Ordering point for LDS traffic WITHIN one wavefront: the LDS executes a wave's instructions in issue order, so a
+// ds_read issued after a ds_write of the same wave observes it without an s_waitcnt in between; all that is needed is
+// that the compiler keeps the program order (HOMMX_SWEEP_WAIT restores the full wait, for A/B runs).
+__device__ __forceinline__ void lds_order() {
+#ifdef HOMMX_SWEEP_WAIT
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 struct SyncBlock {
   static __device__ __forceinline__ void sync() { __syncthreads(); }
 };
@@ -121,14 +162,19 @@ struct SweepStepBlk {
     constexpr int K1 = more ? K + 1 : K;
     constexpr int kb1 = K1 / BS, kr1 = K1 % BS;
     bad |= !(d > 0.0);
-    __syncthreads();
+    lds_order();  // the reads below queue behind this wave's own ubuf stores: no wait for their completion
     double ur[BS], uc[BS], t[BS];
 #pragma unroll
     for (int q = 0; q < BS; q += 2) {
+#ifdef HOMMX_ABLATE_SWEEPLDS  // timing experiment only (wrong results): no LDS traffic in the sweep
+      ur[q] = s[q]; ur[q + 1] = s[q + 1];
+      uc[q] = s[BS + q]; uc[q + 1] = s[BS + q + 1];
+#else
       const double2 a = *reinterpret_cast<const double2*>(&ubuf[BS * bi + q]);
       const double2 b = *reinterpret_cast<const double2*>(&ubuf[BS * bj + q]);
       ur[q] = a.x; ur[q + 1] = a.y;
       uc[q] = b.x; uc[q + 1] = b.y;
+#endif
     }
 #pragma unroll
     for (int r = 0; r < BS; ++r) t[r] = ur[r] * pinv;  // scaled pivot-row entries at my rows (== new pivot column)
