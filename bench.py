@@ -44,7 +44,7 @@ def algorithmic_bytes(n: int, stratified: bool) -> float:
 
 
 def cpu_baseline(coef: np.ndarray, n: int, vols_X: np.ndarray, budget_s: float = 15.0):
-    """Reference-shaped CPU path (oracle, 1 core) on a bounded sample of the same workload."""
+    """Reference-shaped CPU path (oracle, one core) on a bounded sample: cells coef[0], coef[1], ... until the budget."""
     from oracle import hommx_oracle as O
 
     t0 = time.perf_counter()
@@ -61,6 +61,44 @@ def cpu_baseline(coef: np.ndarray, n: int, vols_X: np.ndarray, budget_s: float =
     return done / dt, done, np.stack(AH)
 
 
+def cpu_worker(args):
+    """Child process of the multi-core CPU baseline: `bench.py --cpu-worker START COUNT` runs the one-core loop on its own
+    slice of the same workload (the reference partitions the macro cells over MPI ranks the same way, hmm.py:307-310)
+    and prints {"done", "seconds"}.  Never touches the GPU."""
+    from hommx_amd import workloads
+
+    start, count = args.cpu_worker
+    msh, coef_h, _ = workloads.c2_inclusion(args.macro, args.micro)
+    X = msh.cell_vertices()
+    rate, done, _ = cpu_baseline(coef_h[start : start + count], args.micro, X[start : start + count], args.cpu_budget)
+    print(json.dumps({"done": done, "seconds": done / rate}))
+
+
+def cpu_baseline_multicore(args, coef_h, n, X, cores: int):
+    """`cores` one-core loops side by side (this process is one of them and keeps its tensors for the parity check).
+    Rate = all cells done / the slowest worker's time."""
+    import subprocess
+
+    nc = coef_h.shape[0]
+    per = nc // cores
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    kids = [
+        subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(w * per), str(per), "--macro", str(args.macro),
+             "--micro", str(n), "--cpu-budget", str(args.cpu_budget)],
+            stdout=subprocess.PIPE, text=True, env=env)
+        for w in range(1, cores)
+    ]
+    rate0, done0, AH = cpu_baseline(coef_h[:per], n, X[:per], args.cpu_budget)
+    done, slowest = done0, done0 / rate0
+    for k in kids:
+        out, _ = k.communicate(timeout=600)
+        r = json.loads(out.strip().splitlines()[-1])
+        done += r["done"]
+        slowest = max(slowest, r["seconds"])
+    return done / slowest, done, done0, AH
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +107,12 @@ def main():
     ap.add_argument("--macro", type=int, default=64, help="macro cells per side (C2: 64)")
     ap.add_argument("--micro", type=int, default=32, help="micro cells per side (C2: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0: min(16, available))")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per core")
+    ap.add_argument("--cpu-worker", type=int, nargs=2, metavar=("START", "COUNT"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
 
     import torch
 
@@ -200,17 +243,20 @@ def main():
             print(f"[bench] calibration failed: {e}", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             X = msh.cell_vertices()
-            rate, ndone, AH_cpu = cpu_baseline(coef_h, n, X)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = args.cpu_cores if args.cpu_cores > 0 else min(16, avail)
+            rate, ntotal, ndone, AH_cpu = cpu_baseline_multicore(args, coef_h, n, X, cores)
             AH_gpu = field[:ndone].cpu().numpy()
             err = float(np.max(np.linalg.norm(AH_gpu - AH_cpu, axis=(1, 2)) / np.linalg.norm(AH_cpu, axis=(1, 2))))
             rec["cpu_baseline"] = {
                 "value": rate,
                 "unit": "solves/s",
-                "cores": 1,
+                "cores": cores,
                 "kind": "port",
-                "sample": f"first {ndone} macro cells of the same batch; oracle restatement of hmm.py:334-369 "
-                "(3 corrector solves + 9 energies per cell, SciPy splu), host cores available: "
-                f"{os.cpu_count()}",
+                "sample": f"{ntotal} macro cells of the same batch in {cores} equal slices, one process per core "
+                f"({args.cpu_budget:g} s budget each; the reference partitions cells over MPI ranks the same way); oracle "
+                "restatement of hmm.py:334-369 (3 corrector solves + 9 energies per cell, SciPy splu); host cores "
+                f"available to this process: {avail}",
             }
             rec["effective_tensor_max_rel_err_vs_oracle"] = err
         print(json.dumps(rec))
