@@ -153,7 +153,10 @@ def main():
         if ev is not None:
             ev[1].record(stream)
         if use_dist:
-            return all_gather_field(out, world * nc)
+            full = all_gather_field(out, world * nc)
+            if ev is not None:
+                ev[2].record(stream)  # the current stream waits for the collective: [1] -> [2] is the all-gather
+            return full
         return out
 
     for _ in range(args.warmup):
@@ -162,7 +165,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         field = step(evs[k])
@@ -175,7 +178,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))  # HIP events on the launch stream
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # HIP events on the launch stream
+    ag_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if use_dist else None
     n_bad = int((info != 0).sum().item())
 
     if rank == 0:
@@ -193,6 +197,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
+            "allgather_ms": ag_ms,  # RCCL all-gather of the A_H field per step; null without a process group
             "dtype": "f64",
             "data": "synthetic",
             "config": {
