@@ -39,6 +39,13 @@ extern "C" {
 #define HOMMX_KIND_ELASTICITY_VOIGT 3   /* same forms, full Hooke tensor; coef[cell][el][t(t+1)/2], upper triangle of
                                            the t x t matrix  E^m : A : E^n  (tensorial unit strains), row-major */
 
+#define HOMMX_FLAG_FORCE_BLOCKED 1     /* use the generic blocked kernel family even where the fused 2D kernel applies */
+
+/* Environment knobs (development / tuning; read once per process):
+ *   HOMMX_BLOCKED_MEM_GB   workspace budget of the blocked family in GB (default min(64, half of the free HBM))
+ *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256)
+ *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products                              */
+
 typedef struct hommx_plan hommx_plan;
 
 typedef struct hommx_plan_desc {
@@ -46,7 +53,7 @@ typedef struct hommx_plan_desc {
   int32_t n_micro;  /* micro cells per side of the unit-cell mesh create_unit_square/cube(n,n[,n]) */
   int32_t kind;     /* HOMMX_KIND_*                                                                */
   int32_t device;   /* HIP device ordinal                                                          */
-  int32_t flags;    /* reserved, 0                                                                 */
+  int32_t flags;    /* HOMMX_FLAG_* bits, normally 0                                               */
   int32_t reserved[3];
 } hommx_plan_desc;
 
