@@ -850,6 +850,34 @@ __global__ __launch_bounds__(64) void k_leaf_inverse(double* __restrict__ S, int
   if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
 }
 
+// same for NB = 64 in the block layout of sweep_blk (lane = 8x8 block, 128 VGPRs of matrix): one launch instead of the
+// two 32-leaves, four GEMMs and their launch latencies of a 64-node of the recursion.  Reads the LOWER triangle only
+// (blocks above the diagonal are mirrored on the way in), writes the full symmetric inverse.
+template <int NB>
+__global__ __launch_bounds__(64) void k_leaf_inverse_blk(double* __restrict__ S, int ld, long long stride, int off,
+                                                         int32_t* __restrict__ info, int stepcode) {
+  constexpr int BS = NB / 8;
+  __shared__ alignas(16) double ubuf[NB];
+  const long long cell = blockIdx.x;
+  const int l = threadIdx.x, bi = l >> 3, bj = l & 7;
+  double* P = S + cell * stride + (long long)off * ld + off;
+  double s[BS * BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int q = 0; q < BS; ++q) {
+      const int row = BS * bi + r, col = BS * bj + q;
+      s[r * BS + q] = (bi >= bj) ? P[(long long)row * ld + col] : P[(long long)col * ld + row];
+    }
+  int bad = 0;
+  sweep_blk<NB>(s, ubuf, bi, bj, bad);
+#pragma unroll
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int q = 0; q < BS; ++q) P[(long long)(BS * bi + r) * ld + BS * bj + q] = -s[r * BS + q];
+  if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
+}
+
 // two-phase media: expand (mask, per-cell phase values) into the element stream the assembly reads
 __global__ void k_expand_two_phase(const unsigned char* __restrict__ mask, const double* __restrict__ values,
                                    double* __restrict__ coef, long long n_el, int n_comp, long long ncells) {
@@ -1263,6 +1291,10 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
       hipLaunchKernelGGL(k_leaf_inverse<32>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
     else
       hipLaunchKernelGGL(k_leaf_inverse<16>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
+    return;
+  }
+  if (size == 64 && !getenv("HOMMX_LEAF32")) {
+    hipLaunchKernelGGL(k_leaf_inverse_blk<64>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
     return;
   }
   int s1 = (size / 2) / 32 * 32;
