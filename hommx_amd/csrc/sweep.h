@@ -17,6 +17,21 @@ struct Cfg {
   static constexpr int KK = NB / 4;         // k-steps of the 16x16x4 MFMA
 };
 
+// "not a usable pivot" (d <= 0, denormal, inf or NaN) of a wave-uniform double, in integer arithmetic on its high word:
+// d comes out of v_readlane, i.e. out of SGPRs, and this keeps the test on the scalar unit (a v_cmp_f64 per pivot is a
+// VALU issue slot, and those are what the sweep is short of).
+__device__ __forceinline__ int bad_pivot_hi(int hi) {
+  return (unsigned)(hi - 1) >= 0x7fefffffu;  // hi in [0x00000001, 0x7fefffff] <=> positive normal finite
+}
+__device__ __forceinline__ int bad_pivot(double d) { return bad_pivot_hi(__double2hiint(d)); }
+// v_readlane of a double that also flags an unusable pivot, tested on the SGPR the high word arrives in
+__device__ __forceinline__ double readlane_pivot(double v, int lane, int& bad) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  bad |= bad_pivot_hi(hi);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -103,7 +118,7 @@ struct SweepStep {
     constexpr int RPL = Cfg<NB>::RPL;
     constexpr int gk = K / RPL, ik = K % RPL;
     const double d = readlane_f64(s[ik], gk * NB + K);
-    bad |= !(d > 0.0);
+    bad |= bad_pivot(d);
     const double pinv = fast_rcp(d);
     if (g == gk) {
       const double u = s[ik];
@@ -161,7 +176,6 @@ struct SweepStepBlk {
     constexpr bool more = (K + 1 < NB);
     constexpr int K1 = more ? K + 1 : K;
     constexpr int kb1 = K1 / BS, kr1 = K1 % BS;
-    bad |= !(d > 0.0);
     lds_order();  // the reads below queue behind this wave's own ubuf stores: no wait for their completion
     double ur[BS], uc[BS], t[BS];
 #pragma unroll
@@ -191,7 +205,7 @@ struct SweepStepBlk {
 #pragma unroll
         for (int q = 0; q < BS; q += 2) *reinterpret_cast<double2*>(&ubuf[BS * bj + q]) = double2{e[q], e[q + 1]};
       }
-      dn = readlane_f64(e[kr1], 9 * kb1);
+      dn = readlane_pivot(e[kr1], 9 * kb1, bad);
       pn = pin_here(fast_rcp(dn));
     }
 #pragma unroll
@@ -227,8 +241,10 @@ __device__ __forceinline__ void sweep_blk(double (&s)[(NB / 8) * (NB / 8)], doub
 #pragma unroll
     for (int q = 0; q < BS; q += 2) *reinterpret_cast<double2*>(&ubuf[BS * bj + q]) = double2{s[q], s[q + 1]};
   }
-  const double d0 = readlane_f64(s[0], 0);
-  SweepStepBlk<NB, 0>::run(s, ubuf, bi, bj, bad, d0, fast_rcp(d0));
+  int ub = 0;  // wave-uniform flag (fed by v_readlane results only): stays on the scalar unit until the single OR below
+  const double d0 = readlane_pivot(s[0], 0, ub);
+  SweepStepBlk<NB, 0>::run(s, ubuf, bi, bj, ub, d0, fast_rcp(d0));
+  bad |= ub;
 }
 
 }  // namespace hommx
