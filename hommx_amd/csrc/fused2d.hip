@@ -69,7 +69,9 @@ struct alignas(16) Lds {
   double e0[NB];         // E[r][r]
   double e1[NB];         // E[r][r-1]
   double vcol[NB];       // V'[:, n-1]: the wrap-around neighbour column of W_next
+#ifdef HOMMX_SL_IN_LDS
   double slbuf[NB * NB]; // S_last accumulators parked between two S_last updates (lane-private slots)
+#endif
 };
 
 template <int NB>
@@ -193,6 +195,9 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   // ---- prologue: rows n-2, n-1, 0 ---------------------------------------------------------------
   double wf[NT][KK];  // W, operand layout
   double s[RPL];      // S, BLK layout (RPL == BS * BS)
+#ifndef HOMMX_SL_IN_LDS
+  d4 slr[NT][NT];     // S_last accumulators (lower tiles) resident in registers instead of LDS slots
+#endif
   double rr[2], rl[2];
   CoefRow cur;
   // C0 = int_Y A (the corrector-free part of hmm.py:652-667) is accumulated while the coefficient lines stream by:
@@ -210,7 +215,13 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.slbuf[((ti * NT + tj) * 4 + r) * 64 + l] = L.mat[TILE(tj, 16 * ti + 4 * r)];
+        for (int r = 0; r < 4; ++r) {
+#ifndef HOMMX_SL_IN_LDS
+          if (tj <= ti) slr[ti][tj][r] = L.mat[TILE(tj, 16 * ti + 4 * r)];
+#else
+          L.slbuf[((ti * NT + tj) * 4 + r) * 64 + l] = L.mat[TILE(tj, 16 * ti + 4 * r)];
+#endif
+        }
     __syncthreads();
     // W_0 = K[(., n-1), (., 0)] = U_{n-1}
     band_X_to_matT(st_N(rowB), st_NE(rowB), true);
@@ -298,9 +309,13 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     }
 
 #ifndef HOMMX_ABLATE_GEMM2
-    // (4) S_last += V' W^T.  The accumulators (C layout) live in lane-private LDS slots between two updates.
-    //     S_last is symmetric: only the tiles on and below the diagonal are kept (3 of 4 for NB = 32).
+    // (4) S_last += V' W^T.  The accumulators (C layout) stay in registers across the whole elimination (24 VGPRs for
+    //     NB = 32; -DHOMMX_SL_IN_LDS parks them in lane-private LDS slots instead, the layout used while the kernel
+    //     still spilled).  S_last is symmetric: only the tiles on and below the diagonal are kept (3 of 4 for NB = 32).
     {
+#ifndef HOMMX_SL_IN_LDS
+      d4 (&sl)[NT][NT] = slr;
+#else
       d4 sl[NT][NT];
 #pragma unroll
       for (int a = 0; a < NT; ++a)
@@ -308,6 +323,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
         for (int b = 0; b <= a; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) sl[a][b][r] = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
+#endif
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -315,12 +331,14 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #pragma unroll
           for (int b = 0; b <= a; ++b)
             sl[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk >> 2][a][kk & 3], wf[b][kk], sl[a][b], 0, 0, 0);
+#ifdef HOMMX_SL_IN_LDS
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b <= a; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) L.slbuf[((a * NT + b) * 4 + r) * 64 + l] = sl[a][b][r];
+#endif
     }
 
 #endif
@@ -500,7 +518,11 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     for (int b = 0; b <= a; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+#ifndef HOMMX_SL_IN_LDS
+        const double v = slr[a][b][r];
+#else
         const double v = L.slbuf[((a * NT + b) * 4 + r) * 64 + l];
+#endif
         L.mat[TILE(b, 16 * a + 4 * r)] = v;                                          // (16a + l4 + 4r, 16b + l15)
         if (b < a) L.mat[midx<NB>(16 * b + l15, 16 * a + 4 * r + l4)] = v;           // mirror image
       }
