@@ -159,6 +159,53 @@ struct SweepStep<NB, NB, SYNC> {
 
 namespace hommx {
 
+// ---- predicated fix-ups with COMPILE-TIME exec masks ---------------------------------------------------------------
+// In the block layout the lanes of block row / column k are known constants (bi = l >> 3, bj = l & 7), so the pivot
+// row / column fix-ups can run under a literal exec mask instead of one the compiler derives from v_cmp and has to
+// keep in (or spill from) SGPRs for all 8 + 8 values of k.  exec is saved and restored inside the one asm statement.
+template <int KB> struct LaneMask {
+  static constexpr unsigned col_lo = 0x01010101u << KB, col_hi = 0x01010101u << KB;              // bj == KB
+  static constexpr unsigned row_lo = KB < 4 ? 0xFFu << (8 * (KB & 3)) : 0u;                      // bi == KB
+  static constexpr unsigned row_hi = KB < 4 ? 0u : 0xFFu << (8 * (KB & 3));
+  static constexpr unsigned dia_lo = KB < 4 ? 1u << ((9 * KB) & 31) : 0u;                        // lane 9 KB
+  static constexpr unsigned dia_hi = KB < 4 ? 0u : 1u << ((9 * KB - 32) & 31);
+};
+#define HOMMX_EXEC_IN "s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_lo, %[lo]\n\ts_mov_b32 exec_hi, %[hi]\n\t"
+#define HOMMX_EXEC_OUT "s_mov_b64 exec, %[sv]"
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_mov(double& d, double v) {
+  unsigned long long sv;
+  asm(HOMMX_EXEC_IN "v_mov_b64 %[d], %[v]\n\t" HOMMX_EXEC_OUT
+      : [d] "+v"(d), [sv] "=&s"(sv) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
+}
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_mov4(double& d0, double& d1, double& d2, double& d3, double v0, double v1, double v2,
+                                            double v3) {
+  unsigned long long sv;
+  asm(HOMMX_EXEC_IN "v_mov_b64 %[d0], %[v0]\n\tv_mov_b64 %[d1], %[v1]\n\tv_mov_b64 %[d2], %[v2]\n\tv_mov_b64 %[d3], %[v3]\n\t"
+      HOMMX_EXEC_OUT
+      : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [sv] "=&s"(sv)
+      : [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [lo] "i"(LO), [hi] "i"(HI));
+}
+// d_q = u_q * p on the lanes of (LO, HI)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_scale4(double& d0, double& d1, double& d2, double& d3, double u0, double u1, double u2,
+                                              double u3, double p) {
+  unsigned long long sv;
+  asm(HOMMX_EXEC_IN
+      "v_mul_f64 %[d0], %[u0], %[p]\n\tv_mul_f64 %[d1], %[u1], %[p]\n\tv_mul_f64 %[d2], %[u2], %[p]\n\t"
+      "v_mul_f64 %[d3], %[u3], %[p]\n\t" HOMMX_EXEC_OUT
+      : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3), [sv] "=&s"(sv)
+      : [u0] "v"(u0), [u1] "v"(u1), [u2] "v"(u2), [u3] "v"(u3), [p] "v"(p), [lo] "i"(LO), [hi] "i"(HI));
+}
+// d = -p on the lanes of (LO, HI)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_neg(double& d, double p) {
+  unsigned long long sv;
+  asm(HOMMX_EXEC_IN "v_mul_f64 %[d], -1.0, %[p]\n\t" HOMMX_EXEC_OUT
+      : [d] "+v"(d), [sv] "=&s"(sv) : [p] "v"(p), [lo] "i"(LO), [hi] "i"(HI));
+}
+
 // ---- same sweep, "BLK layout": lane l owns the BS x BS block (bi = l >> 3, bj = l & 7), BS = NB / 8 ----------
 // Element (r, q) of the block is matrix entry (BS*bi + r, BS*bj + q) and lives in s[r * BS + q].
 // Per pivot a lane needs only BS entries of the pivot row for its rows and BS for its columns (2*BS LDS
@@ -198,6 +245,10 @@ struct SweepStepBlk {
       double e[BS];
 #pragma unroll
       for (int q = 0; q < BS; ++q) e[q] = fma(-t[kr1], uc[q], s[kr1 * BS + q]);
+#ifndef HOMMX_NO_ASM_MASKS
+      if constexpr (BS == 4) masked_mov<LaneMask<kb>::col_lo, LaneMask<kb>::col_hi>(e[kr], t[kr1]);
+      else
+#endif
       if (bj == kb) e[kr] = t[kr1];
 #pragma unroll
       for (int q = 0; q < BS; ++q) s[kr1 * BS + q] = e[q];
@@ -214,14 +265,25 @@ struct SweepStepBlk {
 #pragma unroll
         for (int q = 0; q < BS; ++q) s[r * BS + q] = fma(-t[r], uc[q], s[r * BS + q]);
       }
-    if (bj == kb) {  // pivot column
+#ifndef HOMMX_NO_ASM_MASKS
+    if constexpr (BS == 4) {
+      using LM = LaneMask<kb>;
+      masked_mov4<LM::col_lo, LM::col_hi>(s[0 * BS + kr], s[1 * BS + kr], s[2 * BS + kr], s[3 * BS + kr], t[0], t[1], t[2], t[3]);
+      masked_scale4<LM::row_lo, LM::row_hi>(s[kr * BS + 0], s[kr * BS + 1], s[kr * BS + 2], s[kr * BS + 3], uc[0], uc[1], uc[2],
+                                            uc[3], pinv);
+      masked_neg<LM::dia_lo, LM::dia_hi>(s[kr * BS + kr], pinv);
+    } else
+#endif
+    {
+      if (bj == kb) {  // pivot column
 #pragma unroll
-      for (int r = 0; r < BS; ++r) s[r * BS + kr] = t[r];
-    }
-    if (bi == kb) {  // pivot row: scaled raw row; (K, K) = -1/pivot
+        for (int r = 0; r < BS; ++r) s[r * BS + kr] = t[r];
+      }
+      if (bi == kb) {  // pivot row: scaled raw row; (K, K) = -1/pivot
 #pragma unroll
-      for (int q = 0; q < BS; ++q) s[kr * BS + q] = uc[q] * pinv;
-      if (bj == kb) s[kr * BS + kr] = -pinv;
+        for (int q = 0; q < BS; ++q) s[kr * BS + q] = uc[q] * pinv;
+        if (bj == kb) s[kr * BS + kr] = -pinv;
+      }
     }
     SweepStepBlk<NB, K + 1>::run(s, ubuf, bi, bj, bad, dn, pn);
   }
