@@ -438,7 +438,13 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
             double vv = (kk == 0) ? uu : carry;
             swap32(vv, uu);  // vv = [., ., x1, x1], uu = [prev x3, prev x3, x3, x3]
             carry = uu;
+#ifndef HOMMX_NO_ASM_MASKS
+            double z = tt;                                                   // rows 1, 3 (rows 0, 2 overwritten below)
+            masked_mov<0u, 0x0000FFFFu>(z, vv);                              // row 2 = lanes 32..47
+            masked_mov<0x0000FFFFu, 0u>(z, (kk == 0) ? wrapv : uu);          // row 0 = lanes  0..15
+#else
             const double z = (l4 & 1) ? tt : ((l4 == 2) ? vv : ((kk == 0) ? wrapv : uu));
+#endif
             wf[t][kk] = fma(z, f1[kk], x * f0[kk]);
             {  // one register at a time (hoisted, the swap temporaries of all kk spill): the next swap32 waits for this fma
               int clo = __double2loint(carry);
