@@ -702,110 +702,6 @@ __global__ __launch_bounds__(256) void k_center_corr(Geo G, double* __restrict__
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// batched fp64 MFMA GEMM:  C = alpha op(A) op(B) + beta C,  64x64 tile per 256-thread workgroup, 32x32 per wave
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int GP = 80;  // LDS row pitch (doubles): 160 dwords == 32 mod 64 -> conflict-free ds_read_b64 fragments
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
-                                              long long sA, const double* __restrict__ B, int ldb, long long sB,
-                                              double beta, double* __restrict__ C, int ldc, long long sC,
-                                              int lowerOnly, double* __restrict__ Ct) {
-  if (lowerOnly && blockIdx.x > blockIdx.y) return;  // symmetric result: tiles above the diagonal are mirrored later
-  __shared__ double As[16 * GP];
-  __shared__ double Bs[16 * GP];
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const long long cell = blockIdx.z;
-  A += cell * sA;
-  B += cell * sB;
-  C += cell * sC;
-  if (Ct) Ct += cell * sC;
-  const int wi0 = 32 * (w >> 1), wj0 = 32 * (w & 1);
-  const int l15 = l & 15, l4 = l >> 4;
-  d4 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
-
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    // ---- stage A tile: As[k][i], i in [0,64), k in [0,16)
-    if (!TA) {
-      const int i = tid >> 2, kq = (tid & 3) * 4;
-      double v[4] = {0.0, 0.0, 0.0, 0.0};
-      if (m0 + i < M) {
-        const double* p = A + (long long)(m0 + i) * lda + k0 + kq;
-        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
-        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) As[(kq + x) * GP + i] = v[x];
-    } else {
-      const int k = tid >> 4, iq = (tid & 15) * 4;
-      double v[4] = {0.0, 0.0, 0.0, 0.0};
-      if (m0 + iq < M) {
-        const double* p = A + (long long)(k0 + k) * lda + m0 + iq;
-        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
-        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) As[k * GP + iq + x] = v[x];
-    }
-    // ---- stage B tile: Bs[k][j]
-    if (!TB) {
-      const int k = tid >> 4, jq = (tid & 15) * 4;
-      double v[4] = {0.0, 0.0, 0.0, 0.0};
-      if (n0 + jq < N) {
-        const double* p = B + (long long)(k0 + k) * ldb + n0 + jq;
-        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
-        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) Bs[k * GP + jq + x] = v[x];
-    } else {
-      const int j = tid >> 2, kq = (tid & 3) * 4;
-      double v[4] = {0.0, 0.0, 0.0, 0.0};
-      if (n0 + j < N) {
-        const double* p = B + (long long)(n0 + j) * ldb + k0 + kq;
-        const double2 p0 = *reinterpret_cast<const double2*>(p), p1 = *reinterpret_cast<const double2*>(p + 2);
-        v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) Bs[(kq + x) * GP + j] = v[x];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      double af[2], bf[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = As[(4 * ks + l4) * GP + wi0 + 16 * a + l15];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) bf[b] = Bs[(4 * ks + l4) * GP + wj0 + 16 * b + l15];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
-        if (row < M && col < N) {
-          double* p = C + (long long)row * ldc + col;
-          double v = alpha * acc[a][b][r];
-          if (beta != 0.0) v += beta * *p;
-          *p = v;
-          if (Ct) Ct[(long long)col * ldc + row] = v;  // mirrored copy (same leading dimension and batch stride as C)
-        }
-      }
-}
 
 // A[i][j] = A[j][i] for j > i  (mirror the lower triangle; batched, ld = N)
 __global__ void k_symmetrize(int N, double* __restrict__ A, long long sA, long long ncells) {
@@ -1068,22 +964,27 @@ static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// large-tile variant: 128x128 per 256-thread workgroup (64x64 = 4x4 MFMA tiles per wave), K staged 16 at a time
-// with the next stage prefetched into registers while the current one is multiplied.  Halves the L2 -> LDS traffic
-// per flop of the 64x64 kernel (16 vs 8 flop/B), which is what bounds that kernel once the panels of the ~14 cells
-// in flight no longer fit the 4 MB L2 of an XCD.  The grid is one-dimensional and XCD-aware: workgroup g runs on XCD
-// g % 8 (round-robin dispatch), so cell = 8 * (slot / T) + g % 8 keeps ALL tiles of one cell on one XCD's L2.
+// batched fp64 MFMA GEMM  C = alpha op(A) op(B) + beta C  (v_mfma_f64_16x16x4_f64), TM x TM tile per 256-thread
+// workgroup, (TM/2)^2 per wave: TM = 128 (4x4 MFMA tiles, 128 accumulator VGPRs per wave; 16 flop per byte of
+// L2 -> LDS traffic) for M, N >= 256, TM = 64 for the small levels of the recursive inverse and the 16-row load
+// products.  K is staged 16 at a time with the next stage prefetched into registers while the current one is
+// multiplied; LDS pitch TM + 16 doubles (== 32 dwords mod 64: conflict-free ds_read_b64 fragments).  The grid is
+// one-dimensional and XCD-aware: workgroup g runs on XCD g % 8 (round-robin dispatch), so
+// cell = 8 * (slot / T) + g % 8 keeps ALL tiles of one cell on one XCD's 4 MB L2; symmetric updates enumerate the
+// lower-triangle tiles only; an optional mirrored store (Ct) writes C^T as well, which replaces transpose passes.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int GP2 = 144;  // 288 dwords == 32 mod 64, as GP
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double alpha, const double* __restrict__ A,
+template <bool TA, bool TB, int TM>
+__global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, double alpha, const double* __restrict__ A,
                                                     int lda, long long sA, const double* __restrict__ B, int ldb,
                                                     long long sB, double beta, double* __restrict__ C, int ldc,
                                                     long long sC, int lowerOnly, int nc, int tilesX, int tilesPerCell,
                                                     double* __restrict__ Ct) {
-  __shared__ double As[16 * GP2];
-  __shared__ double Bs[16 * GP2];
+  constexpr int PITCH = TM + 16;  // 2 PITCH dwords == 32 mod 64 for TM = 64 and 128: conflict-free ds_read_b64 fragments
+  constexpr int WT = TM / 2;      // per-wave tile
+  constexpr int NF = WT / 16;     // 16x16 MFMA tiles per wave and dimension
+  constexpr int PT = TM / 16;     // doubles per thread, operand and 16-deep stage
+  __shared__ double As[16 * PITCH];
+  __shared__ double Bs[16 * PITCH];
   const int g = blockIdx.x, slot = g >> 3;
   const long long cell = 8ll * (slot / tilesPerCell) + (g & 7);
   if (cell >= nc) return;
@@ -1098,31 +999,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double 
     tx = tile % tilesX;
   }
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-  const int m0 = ty * 128, n0 = tx * 128;
+  const int m0 = ty * TM, n0 = tx * TM;
   A += cell * sA;
   B += cell * sB;
   C += cell * sC;
   if (Ct) Ct += cell * sC;
-  const int wi0 = 64 * (w >> 1), wj0 = 64 * (w & 1);
+  const int wi0 = WT * (w >> 1), wj0 = WT * (w & 1);
   const int l15 = l & 15, l4 = l >> 4;
-  d4 acc[4][4];
+  d4 acc[NF][NF];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NF; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NF; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
   // staging maps.  "row-major along k" operand (A not transposed / B transposed): thread -> row t >> 1, 8 k's;
   // "k-major" operand (A transposed / B not transposed): thread -> k = t >> 4, 8 consecutive rows.
-  const int rk_row = tid >> 1, rk_k = (tid & 1) * 8;
-  const int km_k = tid >> 4, km_row = (tid & 15) * 8;
-  double pa[8], pb[8];
+  constexpr int TPR = 16 / PT;  // threads per tile row in the row-major-along-k map
+  const int rk_row = tid / TPR, rk_k = (tid % TPR) * PT;
+  const int km_k = tid >> 4, km_row = (tid & 15) * PT;
+  double pa[PT], pb[PT];
   auto fetch = [&](int k0) {
     const double* p;
     bool ok;
     if (!TA) { ok = m0 + rk_row < M; p = A + (long long)(m0 + rk_row) * lda + k0 + rk_k; }
     else     { ok = m0 + km_row < M; p = A + (long long)(k0 + km_k) * lda + m0 + km_row; }
 #pragma unroll
-    for (int x = 0; x < 8; x += 2) {
+    for (int x = 0; x < PT; x += 2) {
       double2 v = double2{0.0, 0.0};
       if (ok) v = *reinterpret_cast<const double2*>(p + x);
       pa[x] = v.x; pa[x + 1] = v.y;
@@ -1130,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double 
     if (TB) { ok = n0 + rk_row < N; p = B + (long long)(n0 + rk_row) * ldb + k0 + rk_k; }
     else    { ok = n0 + km_row < N; p = B + (long long)(k0 + km_k) * ldb + n0 + km_row; }
 #pragma unroll
-    for (int x = 0; x < 8; x += 2) {
+    for (int x = 0; x < PT; x += 2) {
       double2 v = double2{0.0, 0.0};
       if (ok) v = *reinterpret_cast<const double2*>(p + x);
       pb[x] = v.x; pb[x + 1] = v.y;
@@ -1139,17 +1041,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double 
   auto stash = [&]() {
     if (!TA) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) As[(rk_k + x) * GP2 + rk_row] = pa[x];
+      for (int x = 0; x < PT; ++x) As[(rk_k + x) * PITCH + rk_row] = pa[x];
     } else {
 #pragma unroll
-      for (int x = 0; x < 8; x += 2) *reinterpret_cast<double2*>(&As[km_k * GP2 + km_row + x]) = double2{pa[x], pa[x + 1]};
+      for (int x = 0; x < PT; x += 2) *reinterpret_cast<double2*>(&As[km_k * PITCH + km_row + x]) = double2{pa[x], pa[x + 1]};
     }
     if (TB) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) Bs[(rk_k + x) * GP2 + rk_row] = pb[x];
+      for (int x = 0; x < PT; ++x) Bs[(rk_k + x) * PITCH + rk_row] = pb[x];
     } else {
 #pragma unroll
-      for (int x = 0; x < 8; x += 2) *reinterpret_cast<double2*>(&Bs[km_k * GP2 + km_row + x]) = double2{pb[x], pb[x + 1]};
+      for (int x = 0; x < PT; x += 2) *reinterpret_cast<double2*>(&Bs[km_k * PITCH + km_row + x]) = double2{pb[x], pb[x + 1]};
     }
   };
 
@@ -1161,15 +1063,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double 
     if (more) fetch(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      double af[4], bf[4];
+      double af[NF], bf[NF];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = As[(4 * ks + l4) * GP2 + wi0 + 16 * a + l15];
+      for (int a = 0; a < NF; ++a) af[a] = As[(4 * ks + l4) * PITCH + wi0 + 16 * a + l15];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = Bs[(4 * ks + l4) * GP2 + wj0 + 16 * b + l15];
+      for (int b = 0; b < NF; ++b) bf[b] = Bs[(4 * ks + l4) * PITCH + wj0 + 16 * b + l15];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NF; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
     __syncthreads();
     if (more) {
@@ -1178,9 +1080,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(int M, int N, int K, double 
     }
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < NF; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NF; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
@@ -1208,32 +1110,30 @@ inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + b
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
           const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0,
           double* Ct = nullptr) {
-  static const int min128 = [] {  // dev knob: smallest M, N routed to the 128x128 kernel (tests lower it to cover partial tiles)
+  static const int min128 = [] {  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
     const char* e = getenv("HOMMX_GEMM128_MIN");
     return e ? atoi(e) : 256;
   }();
-  if (M >= min128 && N >= min128) {
-    const int tx = (N + 127) / 128, ty = (M + 127) / 128;
-    const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;
-    const long long groups = (c.nc + 7) / 8;
-    dim3 grid((unsigned)(groups * 8 * T)), block(256);
-#define HOMMX_G128(TA_, TB_) hipLaunchKernelGGL((k_gemm128<TA_, TB_>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct)
-    if (!ta && !tb) HOMMX_G128(false, false);
-    else if (!ta && tb) HOMMX_G128(false, true);
-    else if (ta && !tb) HOMMX_G128(true, false);
-    else HOMMX_G128(true, true);
-#undef HOMMX_G128
-    return;
-  }
-  dim3 grid((N + 63) / 64, (M + 63) / 64, (unsigned)c.nc), block(256);
-  if (!ta && !tb)
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
-  else if (!ta && tb)
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
-  else if (ta && !tb)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
-  else
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, lowerOnly, Ct);
+  const bool big = M >= min128 && N >= min128;
+  const int TM = big ? 128 : 64;
+  const int tx = (N + TM - 1) / TM, ty = (M + TM - 1) / TM;
+  const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;
+  const long long groups = (c.nc + 7) / 8;
+  dim3 grid((unsigned)(groups * 8 * T)), block(256);
+#define HOMMX_GT(TA_, TB_)                                                                                                  \
+  do {                                                                                                                      \
+    if (big)                                                                                                                \
+      hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 128>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, \
+                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                         \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 64>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C,  \
+                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                         \
+  } while (0)
+  if (!ta && !tb) HOMMX_GT(false, false);
+  else if (!ta && tb) HOMMX_GT(false, true);
+  else if (ta && !tb) HOMMX_GT(true, false);
+  else HOMMX_GT(true, true);
+#undef HOMMX_GT
 }
 
 void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha,
