@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, doubl
                                                     int lda, long long sA, const double* __restrict__ B, int ldb,
                                                     long long sB, double beta, double* __restrict__ C, int ldc,
                                                     long long sC, int lowerOnly, int nc, int tilesX, int tilesPerCell,
-                                                    double* __restrict__ Ct) {
+                                                    double* Ct) {
   constexpr int PITCH = TM + 16;  // 2 PITCH dwords == 32 mod 64 for TM = 64 and 128: conflict-free ds_read_b64 fragments
   constexpr int WT = TM / 2;      // per-wave tile
   constexpr int NF = WT / 16;     // 16x16 MFMA tiles per wave and dimension
@@ -1091,7 +1091,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, doubl
           double v = alpha * acc[a][b][r];
           if (beta != 0.0) v += beta * *p;
           *p = v;
-          if (Ct) Ct[(long long)col * ldc + row] = v;  // mirrored copy (same leading dimension and batch stride as C)
+          // mirrored copy (same leading dimension and batch stride as C).  With lowerOnly, Ct may be C itself: the tiles
+          // below the diagonal then fill the ones above; diagonal tiles are complete and are not mirrored (two lanes
+          // would write the same entry with values that differ in the last bit).
+          if (Ct && !(lowerOnly && tx == ty)) Ct[(long long)col * ldc + row] = v;
         }
       }
 }
@@ -1211,7 +1214,8 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
                                                                                           //  the recursion below never reads above the diagonal tiles)
   invert(c, S, off + s1, s2, tmp + (long long)s1 * s2);                        // A22 <- (Schur)^-1
   gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sS, 0.0, A21, ld, sS, 0, A12);  // A21 <- -T^-1 Xm, A12 <- A21^T
-  gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A11, ld, sS);   // A11 <- A11^-1 - Xm^T A21
+  gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A11, ld, sS, 1, A11);  // A11 <- A11^-1 - Xm^T A21: symmetric
+                                                                         // (= A11^-1 + Xm^T T^-1 Xm): lower tiles, mirrored in place
 }
 }  // namespace
 
