@@ -54,6 +54,9 @@ struct hommx_plan {
   hommx::BlockedWorkspace* ws = nullptr;
   double* d_expand = nullptr;  // two-phase media on the blocked family: expanded element stream
   int64_t cap_expand = 0;
+  // host-pointer entry point of the fused family: coefficient chunks stream in on s_copy while s_comp solves the previous one
+  hipStream_t s_copy = nullptr, s_comp = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 extern "C" {
@@ -110,6 +113,10 @@ int hommx_plan_destroy(hommx_plan* p) {
   if (p->d_info) hipFree(p->d_info);
   if (p->ws) hommx::blocked_workspace_destroy(p->ws);
   if (p->d_expand) hipFree(p->d_expand);
+  if (p->s_copy) hipStreamDestroy(p->s_copy);
+  if (p->s_comp) hipStreamDestroy(p->s_comp);
+  for (hipEvent_t e : p->ev)
+    if (e) hipEventDestroy(e);
   delete p;
   return HOMMX_OK;
 }
@@ -162,11 +169,36 @@ int hommx_solve_batch(hommx_plan* p, int64_t n_cells, const double* coef, const 
     HIP_TRY(hipMalloc(&p->d_info, sizeof(int32_t) * n_cells));
     p->cap_cells = n_cells;
   }
-  HIP_TRY(hipMemcpy(p->d_coef, coef, sizeof(double) * n_cells * p->n_el * p->n_comp, hipMemcpyHostToDevice));
   if (M) HIP_TRY(hipMemcpy(p->d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
-  int rc = hommx_solve_batch_device(p, n_cells, p->d_coef, M ? p->d_M : nullptr, p->d_out, p->d_info, nullptr);
-  if (rc != HOMMX_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
+  const int64_t per = p->n_el * p->n_comp;
+  constexpr int64_t CH = 2048;  // cells per chunk: one wave per cell fills the 256 CUs x 8 wave slots exactly once
+  if (p->family == FAM_FUSED2D && n_cells >= 2 * CH && !getenv("HOMMX_NO_H2D_OVERLAP")) {
+    // The coefficient stream (16 KiB per cell) costs more PCIe time than the kernel costs GPU time: pipeline it.  The
+    // copies are issued from pageable memory, so each blocks this thread -- while the kernel of the previous chunk,
+    // already queued on the other stream, runs.
+    if (!p->s_copy) {
+      HIP_TRY(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev[0], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev[1], hipEventDisableTiming));
+    }
+    int k = 0;
+    for (int64_t c0 = 0; c0 < n_cells; c0 += CH, k ^= 1) {
+      const int64_t nc = (n_cells - c0 < CH) ? n_cells - c0 : CH;
+      HIP_TRY(hipMemcpyAsync(p->d_coef + c0 * per, coef + c0 * per, sizeof(double) * nc * per, hipMemcpyHostToDevice, p->s_copy));
+      HIP_TRY(hipEventRecord(p->ev[k], p->s_copy));
+      HIP_TRY(hipStreamWaitEvent(p->s_comp, p->ev[k], 0));
+      int rc = hommx_solve_batch_device(p, nc, p->d_coef + c0 * per, M ? p->d_M + c0 * d * d : nullptr, p->d_out + c0 * t * t,
+                                        p->d_info + c0, p->s_comp);
+      if (rc != HOMMX_OK) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(p->s_comp));
+  } else {
+    HIP_TRY(hipMemcpy(p->d_coef, coef, sizeof(double) * n_cells * per, hipMemcpyHostToDevice));
+    int rc = hommx_solve_batch_device(p, n_cells, p->d_coef, M ? p->d_M : nullptr, p->d_out, p->d_info, nullptr);
+    if (rc != HOMMX_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+  }
   HIP_TRY(hipMemcpy(A_eff, p->d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
   if (info) HIP_TRY(hipMemcpy(info, p->d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
   return HOMMX_OK;
