@@ -879,7 +879,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
 static void ws_free_main(BlockedWorkspace* ws) {
   double** ptrs[] = {&ws->Kst, &ws->Brhs, &ws->C0, &ws->S, &ws->W, &ws->Sl, &ws->V, &ws->X, &ws->T, &ws->R, &ws->Rl, &ws->Vr, &ws->Gm};
   for (auto p : ptrs) {
-    if (*p) hipFree(*p);
+    if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   ws->chunk = 0;
@@ -888,7 +888,7 @@ static void ws_free_main(BlockedWorkspace* ws) {
 static void ws_free_hist(BlockedWorkspace* ws) {
   double** ptrs[] = {&ws->hS, &ws->hW, &ws->hR, &ws->Xa, &ws->Xb, &ws->Y};
   for (auto p : ptrs) {
-    if (*p) hipFree(*p);
+    if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   ws->hchunk = 0;
