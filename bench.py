@@ -102,8 +102,8 @@ def cpu_baseline_multicore(args, coef_h, n, X, cores: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--macro", type=int, default=64, help="macro cells per side (C2: 64)")
     ap.add_argument("--micro", type=int, default=32, help="micro cells per side (C2: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
