@@ -38,25 +38,17 @@ def all_gather_field(local, n_cells: int, group=None):
     return full[:n_cells]
 
 
-def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, device=None):
-    """Solve this rank's block of macro cells and all-gather the field (host-array convenience path).
-
-    With an initialised process group the exchange runs over the group's backend (``nccl`` = RCCL on
-    the GPUs, ``gloo`` in the CPU tests, where ``plan`` may be any object with ``.solve`` and ``.t``).
-    Without one it degenerates to ``plan.solve``.
-    """
+def _gather_shards(plan, n_cells: int, solve_range, group=None, device=None):
+    """Run ``solve_range(b, e)`` on this rank's block of cells and all-gather the field over the group's backend."""
     import torch
     import torch.distributed as dist
 
-    n_cells = coef.shape[0]
-    if not (dist.is_available() and dist.is_initialized()):
-        return plan.solve(coef, M)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     b, e, per = shard_range(n_cells, rank, world)
     t = plan.t
     local = np.zeros((per, t, t))
     if e > b:
-        local[: e - b] = plan.solve(coef[b:e], None if M is None else M[b:e])
+        local[: e - b] = solve_range(b, e)
     tl = torch.from_numpy(local)
     if device is None and dist.get_backend(group) == "nccl":  # RCCL moves device memory only
         device = torch.device("cuda", getattr(plan, "device", torch.cuda.current_device()))
@@ -67,3 +59,27 @@ def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, devi
     idx = np.concatenate([np.arange(r * per, r * per + max(0, min(n_cells, (r + 1) * per) - min(n_cells, r * per)))
                           for r in range(world)])
     return full.cpu().numpy()[idx]
+
+
+def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, device=None):
+    """Solve this rank's block of macro cells and all-gather the field (host-array convenience path).
+
+    With an initialised process group the exchange runs over the group's backend (``nccl`` = RCCL on
+    the GPUs, ``gloo`` in the CPU tests, where ``plan`` may be any object with ``.solve`` and ``.t``).
+    Without one it degenerates to ``plan.solve``.
+    """
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return plan.solve(coef, M)
+    return _gather_shards(plan, coef.shape[0], lambda b, e: plan.solve(coef[b:e], None if M is None else M[b:e]), group, device)
+
+
+def solve_sharded_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None, group=None, device=None):
+    """Same for two-phase media (``plan.solve_two_phase``): every rank holds the phase mask, the per-cell phase values shard."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return plan.solve_two_phase(mask, values, M)
+    return _gather_shards(plan, values.shape[0],
+                          lambda b, e: plan.solve_two_phase(mask, values[b:e], None if M is None else M[b:e]), group, device)

@@ -339,11 +339,6 @@ class BaseHMM(ABC):
             self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
         if not hasattr(self._plan, "solve_two_phase"):
             return None
-        import sys
-
-        dist = sys.modules.get("torch.distributed")
-        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return None  # the sharded path goes through the generic element stream
         d = self._tdim
         yb = self._cell_mesh.cell_midpoints()[:, :d].T  # element barycentres
         mask = np.asarray(self._coeff.indicator(yb), dtype=bool)
@@ -351,6 +346,13 @@ class BaseHMM(ABC):
         if (values.ndim == 2) != (kind == "poisson"):
             raise ValueError("TwoPhase values must be scalars for PoissonHMM and Lame(lam, mu) for LinearElasticityHMM")
         M = self._stratification(cells)
+        import sys
+
+        dist = sys.modules.get("torch.distributed")  # only shard when the caller already runs under torch.distributed
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .dist import solve_sharded_two_phase
+
+            return solve_sharded_two_phase(self._plan, mask, values, M), np.zeros(len(cells), dtype=np.int32)
         return self._plan.solve_two_phase(mask, values, M, return_info=True)
 
     def _local_stiffness_from_tensors(self, cells: np.ndarray, AH: np.ndarray) -> np.ndarray:
