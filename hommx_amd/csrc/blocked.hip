@@ -964,25 +964,25 @@ static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// batched fp64 MFMA GEMM  C = alpha op(A) op(B) + beta C  (v_mfma_f64_16x16x4_f64), TM x TM tile per 256-thread
-// workgroup, (TM/2)^2 per wave: TM = 128 (4x4 MFMA tiles, 128 accumulator VGPRs per wave; 16 flop per byte of
-// L2 -> LDS traffic) for M, N >= 256, TM = 64 for the small levels of the recursive inverse and the 16-row load
+// batched fp64 MFMA GEMM  C = alpha op(A) op(B) + beta C  (v_mfma_f64_16x16x4_f64), TM x TM tile per
+// workgroup of NW waves in a 2 x NW/2 grid: TM = 128, NW = 8 (64 x 32 per wave; 16 flop per byte of L2 -> LDS
+// traffic) for M, N >= 256, TM = 64, NW = 4 for the small levels of the recursive inverse and the 16-row load
 // products.  K is staged 16 at a time with the next stage prefetched into registers while the current one is
 // multiplied; LDS pitch TM + 16 doubles (== 32 dwords mod 64: conflict-free ds_read_b64 fragments).  The grid is
 // one-dimensional and XCD-aware: workgroup g runs on XCD g % 8 (round-robin dispatch), so
 // cell = 8 * (slot / T) + g % 8 keeps ALL tiles of one cell on one XCD's 4 MB L2; symmetric updates enumerate the
 // lower-triangle tiles only; an optional mirrored store (Ct) writes C^T as well, which replaces transpose passes.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool TA, bool TB, int TM>
-__global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, double alpha, const double* __restrict__ A,
+template <bool TA, bool TB, int TM, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, double alpha, const double* __restrict__ A,
                                                     int lda, long long sA, const double* __restrict__ B, int ldb,
                                                     long long sB, double beta, double* __restrict__ C, int ldc,
                                                     long long sC, int lowerOnly, int nc, int tilesX, int tilesPerCell,
                                                     double* Ct) {
   constexpr int PITCH = TM + 16;  // 2 PITCH dwords == 32 mod 64 for TM = 64 and 128: conflict-free ds_read_b64 fragments
-  constexpr int WT = TM / 2;      // per-wave tile
-  constexpr int NF = WT / 16;     // 16x16 MFMA tiles per wave and dimension
-  constexpr int PT = TM / 16;     // doubles per thread, operand and 16-deep stage
+  constexpr int WTM = TM / 2, WTN = TM / (NW / 2);  // per-wave tile: waves form a 2 x (NW / 2) grid
+  constexpr int NFA = WTM / 16, NFB = WTN / 16;     // 16x16 MFMA tiles per wave, rows / columns
+  constexpr int PT = TM * 16 / (64 * NW);           // doubles per thread, operand and 16-deep stage
   __shared__ double As[16 * PITCH];
   __shared__ double Bs[16 * PITCH];
   const int g = blockIdx.x, slot = g >> 3;
@@ -1004,19 +1004,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, doubl
   B += cell * sB;
   C += cell * sC;
   if (Ct) Ct += cell * sC;
-  const int wi0 = WT * (w >> 1), wj0 = WT * (w & 1);
+  const int wi0 = WTM * (w / (NW / 2)), wj0 = WTN * (w % (NW / 2));
   const int l15 = l & 15, l4 = l >> 4;
-  d4 acc[NF][NF];
+  d4 acc[NFA][NFB];
 #pragma unroll
-  for (int a = 0; a < NF; ++a)
+  for (int a = 0; a < NFA; ++a)
 #pragma unroll
-    for (int b = 0; b < NF; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NFB; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
   // staging maps.  "row-major along k" operand (A not transposed / B transposed): thread -> row t >> 1, 8 k's;
   // "k-major" operand (A transposed / B not transposed): thread -> k = t >> 4, 8 consecutive rows.
-  constexpr int TPR = 16 / PT;  // threads per tile row in the row-major-along-k map
+  constexpr int TPR = 16 / PT;   // threads per tile row in the row-major-along-k map
+  constexpr int TPK = TM / PT;   // threads per k-row in the k-major map
   const int rk_row = tid / TPR, rk_k = (tid % TPR) * PT;
-  const int km_k = tid >> 4, km_row = (tid & 15) * PT;
+  const int km_k = tid / TPK, km_row = (tid % TPK) * PT;
   double pa[PT], pb[PT];
   auto fetch = [&](int k0) {
     const double* p;
@@ -1063,15 +1064,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, doubl
     if (more) fetch(k0 + 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      double af[NF], bf[NF];
+      double af[NFA], bf[NFB];
 #pragma unroll
-      for (int a = 0; a < NF; ++a) af[a] = As[(4 * ks + l4) * PITCH + wi0 + 16 * a + l15];
+      for (int a = 0; a < NFA; ++a) af[a] = As[(4 * ks + l4) * PITCH + wi0 + 16 * a + l15];
 #pragma unroll
-      for (int b = 0; b < NF; ++b) bf[b] = Bs[(4 * ks + l4) * PITCH + wj0 + 16 * b + l15];
+      for (int b = 0; b < NFB; ++b) bf[b] = Bs[(4 * ks + l4) * PITCH + wj0 + 16 * b + l15];
 #pragma unroll
-      for (int a = 0; a < NF; ++a)
+      for (int a = 0; a < NFA; ++a)
 #pragma unroll
-        for (int b = 0; b < NF; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NFB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
     __syncthreads();
     if (more) {
@@ -1080,9 +1081,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tile(int M, int N, int K, doubl
     }
   }
 #pragma unroll
-  for (int a = 0; a < NF; ++a)
+  for (int a = 0; a < NFA; ++a)
 #pragma unroll
-    for (int b = 0; b < NF; ++b)
+    for (int b = 0; b < NFB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
@@ -1122,15 +1123,17 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
   const int tx = (N + TM - 1) / TM, ty = (M + TM - 1) / TM;
   const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;
   const long long groups = (c.nc + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * T)), block(256);
+  dim3 grid((unsigned)(groups * 8 * T));
+  // 128 tiles: 8 waves per workgroup (2 x 4 grid of 64 x 32 wave tiles, 110 VGPRs, 4 waves per SIMD): +2 % over 4 waves
+  // of 64 x 64; 64 tiles: 4 waves of 32 x 32 (8 waves measured slower)
 #define HOMMX_GT(TA_, TB_)                                                                                                  \
   do {                                                                                                                      \
     if (big)                                                                                                                \
-      hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 128>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, \
-                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                         \
+      hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 128, 8>), grid, dim3(512), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB,   \
+                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                \
     else                                                                                                                    \
-      hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 64>), grid, block, 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C,  \
-                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                         \
+      hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 64, 4>), grid, dim3(256), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB,    \
+                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                \
   } while (0)
   if (!ta && !tb) HOMMX_GT(false, false);
   else if (!ta && tb) HOMMX_GT(false, true);
