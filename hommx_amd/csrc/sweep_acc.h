@@ -1,0 +1,229 @@
+// sweep_acc.h -- in-register Gauss-Jordan exchange sweep of an NB x NB matrix held by ONE wavefront in the layout of the
+// f64 MFMA accumulator ("acc layout"), NB = 16 or 32:
+//
+//     lane l = 16 k + j  (k = l >> 4 "lane row", j = l & 15),   a[ti][tj][r] = T[16 ti + 4 r + k][16 tj + j]
+//
+// Why this layout: (i) register r of tile row ti IS the k-slab (4 ti + r) of the matrix as an MFMA B operand, and -- for a
+// symmetric matrix -- as an A operand, so the inverse feeds the products of the elimination without leaving the register
+// file; (ii) the column multiplier of a rank-1 update, T[row][K] for the lane's own rows, sits in the SAME register in the same
+// 16-lane row, at lane column K % 16: the DP-ALU DPP control `row_newbcast` delivers it inside the FMA itself
+// (v_fmac_f64_dpp, full rate: tools/probe_dpp64.hip), so a pivot costs 16 FMAs + the pivot-row broadcast, no scaling of a
+// pivot column and no LDS read per row.
+//
+// Exchange convention ("conv 3"): for pivot K with d = T[K][K], u = row K:
+//     row K <- -u/d,   column K <- column / d,   T[K][K] <- 1/d,   rest += column (x) (-u/d)
+// After all NB pivots the registers hold T^-1.  The column rule is folded into the rank-1 update by replacing entry K of the
+// broadcast row by 1/d - 1; the row rule is a masked copy of the broadcast row.  The caller carries T = -S (S SPD), so every
+// pivot must be negative, normal and finite.
+//
+// Hazard rule (gfx9): a VGPR written by a VALU instruction must not be read through DPP within the next 2 wait states --
+// the hardware does NOT interlock (tools/probe_dpp64.hip shows the stale read).  All DPP reads therefore live in asm blocks
+// that start with `s_nop 1`, and every write to a matrix register between two blocks is itself inside such a block or
+// precedes its `s_nop`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sweep.h"
+
+namespace hommx {
+namespace accl {
+
+// literal exec masks of the acc layout
+template <int K> struct RowMask {  // lane row K: lanes 16 K .. 16 K + 15
+  static constexpr unsigned lo = K == 0 ? 0x0000FFFFu : K == 1 ? 0xFFFF0000u : 0u;
+  static constexpr unsigned hi = K == 2 ? 0x0000FFFFu : K == 3 ? 0xFFFF0000u : 0u;
+};
+template <int J> struct ColMask {  // lane column J of every lane row
+  static constexpr unsigned lo = (1u << J) | (1u << (16 + J));
+  static constexpr unsigned hi = lo;
+};
+template <int K, int J> struct OneLane {
+  static constexpr int bit = 16 * K + J;
+  static constexpr unsigned lo = bit < 32 ? 1u << (bit & 31) : 0u;
+  static constexpr unsigned hi = bit >= 32 ? 1u << (bit & 31) : 0u;
+};
+
+// d += v on the lanes of (LO, HI)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_add(double& d, double v) {
+  unsigned long long sv;
+  asm(HOMMX_EXEC_IN "v_add_f64 %[d], %[d], %[v]\n\t" HOMMX_EXEC_OUT
+      : [d] "+v"(d), [sv] "=&s"(sv) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
+}
+// d -= v on the lanes of (LO, HI)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_sub(double& d, double v) {
+  unsigned long long sv;
+  asm(HOMMX_EXEC_IN "v_add_f64 %[d], %[d], -%[v]\n\t" HOMMX_EXEC_OUT
+      : [d] "+v"(d), [sv] "=&s"(sv) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
+}
+// LDS store of one double by the lanes of (LO, HI); `addr` is the byte offset in LDS.  In-order with the wave's other LDS
+// traffic (the LDS queue of a wave is FIFO); the compiler's lgkmcnt bookkeeping stays conservative-correct around it.
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_lds_store(unsigned addr, double v) {
+  unsigned long long sv;
+  asm volatile(HOMMX_EXEC_IN "ds_write_b64 %[a], %[v]\n\t" HOMMX_EXEC_OUT
+               : [sv] "=&s"(sv) : [a] "v"(addr), [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI) : "memory");
+}
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ void masked_lds_store2(unsigned addr0, double v0, unsigned addr1, double v1) {
+  unsigned long long sv;
+  asm volatile(HOMMX_EXEC_IN "ds_write_b64 %[a0], %[v0]\n\tds_write_b64 %[a1], %[v1]\n\t" HOMMX_EXEC_OUT
+               : [sv] "=&s"(sv) : [a0] "v"(addr0), [v0] "v"(v0), [a1] "v"(addr1), [v1] "v"(v1), [lo] "i"(LO), [hi] "i"(HI)
+               : "memory");
+}
+
+// byte offset of a __shared__ object in LDS
+template <class T>
+__device__ __forceinline__ unsigned lds_offset(T* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)p;
+}
+
+// "not a usable pivot" of T = -S: d must be negative, normal and finite (tested on the scalar unit, d comes from v_readlane)
+__device__ __forceinline__ int bad_neg_pivot_hi(int hi) { return (unsigned)((hi ^ (int)0x80000000) - 1) >= 0x7fefffffu; }
+__device__ __forceinline__ double readlane_neg_pivot(double v, int lane, int& bad) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  bad |= bad_neg_pivot_hi(hi);
+  return __hiloint2double(hi, lo);
+}
+
+#define HOMMX_BC " row_newbcast:%[jk] row_mask:0xf bank_mask:0xf\n\t"
+// y += bcast(x) * wo ; x += bcast(x) * wk   (x = register of the pivot's column tile, y = the other column tile)
+#define HOMMX_PAIR(X, Y) "v_fmac_f64_dpp %[" Y "], %[" X "], %[wo]" HOMMX_BC "v_fmac_f64_dpp %[" X "], %[" X "], %[wk]" HOMMX_BC
+#define HOMMX_ONE(X) "v_fmac_f64_dpp %[" X "], %[" X "], %[wk]" HOMMX_BC
+// reciprocal of the NEXT pivot interleaved with the updates: v_rcp_f64 + two Newton steps
+#define HOMMX_RCP0 "v_rcp_f64 %[r], %[d]\n\t"
+#define HOMMX_RCPE "v_fma_f64 %[e], -%[d], %[r], 1.0\n\t"
+#define HOMMX_RCPR "v_fma_f64 %[r], %[e], %[r], %[r]\n\t"
+
+template <int NB> struct Sweep;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NB = 32: 2 x 2 tiles, 16 registers per lane
+// ---------------------------------------------------------------------------------------------------------------------
+template <>
+struct Sweep<32> {
+  static constexpr int NB = 32, NT = 2;
+  typedef double Mat[2][2][4];
+
+  // ubuf: LDS, NB doubles, [tj][j]; ub = byte offset of ubuf + 8 j (per lane)
+  template <int K>
+  static __device__ __forceinline__ void step(Mat& a, const double* ubuf, unsigned ub, int j, int& bad, double u0, double u1,
+                                              double pinv) {
+    constexpr int tK = K / 16, jK = K % 16, rK = (K % 16) / 4, kK = K % 4, o = 1 - tK;
+    constexpr bool more = K + 1 < NB;
+    constexpr int K1 = more ? K + 1 : K;
+    constexpr int tK1 = K1 / 16, jK1 = K1 % 16, rK1 = (K1 % 16) / 4, kK1 = K1 % 4;
+    constexpr int E = tK1 * 4 + rK1;  // (tile row, register) holding pivot row K + 1: updated first
+#define PI(i) ((i) < E ? (i) : (i) + 1)
+#define XR(i) a[PI(i) / 4][tK][PI(i) % 4]
+#define YR(i) a[PI(i) / 4][o][PI(i) % 4]
+    // broadcast row: w = -u / d; entry K becomes 1/d - 1 (column rule)
+    double w[2];
+    w[0] = u0 * -pinv;
+    w[1] = u1 * -pinv;
+    masked_mov<ColMask<jK>::lo, ColMask<jK>::hi>(w[tK], pinv - 1.0);
+    double nu0 = 0.0, nu1 = 0.0, pn = 1.0;
+    if constexpr (more) {
+      // the registers of pivot row K + 1 first, then publish it (raw) and fetch the next pivot
+      asm volatile("s_nop 1\n\t" HOMMX_PAIR("x", "y")
+                   : [x] "+v"(a[tK1][tK][rK1]), [y] "+v"(a[tK1][o][rK1])
+                   : [wk] "v"(w[tK]), [wo] "v"(w[o]), [jk] "n"(jK));
+      masked_lds_store2<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[tK1][0][rK1], ub + 128, a[tK1][1][rK1]);
+      const double dn = readlane_neg_pivot(a[tK1][tK1][rK1], 16 * kK1 + jK1, bad);
+      double e;
+      asm volatile("s_nop 1\n\t" HOMMX_RCP0 HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_RCPE HOMMX_PAIR("x2", "y2")
+                       HOMMX_RCPR HOMMX_PAIR("x3", "y3") HOMMX_RCPE HOMMX_PAIR("x4", "y4") HOMMX_RCPR HOMMX_PAIR("x5", "y5")
+                           HOMMX_PAIR("x6", "y6")
+                   : [x0] "+v"(XR(0)), [y0] "+v"(YR(0)), [x1] "+v"(XR(1)), [y1] "+v"(YR(1)), [x2] "+v"(XR(2)), [y2] "+v"(YR(2)),
+                     [x3] "+v"(XR(3)), [y3] "+v"(YR(3)), [x4] "+v"(XR(4)), [y4] "+v"(YR(4)), [x5] "+v"(XR(5)), [y5] "+v"(YR(5)),
+                     [x6] "+v"(XR(6)), [y6] "+v"(YR(6)), [r] "=&v"(pn), [e] "=&v"(e)
+                   : [wk] "v"(w[tK]), [wo] "v"(w[o]), [d] "s"(dn), [jk] "n"(jK));
+      // raw pivot row K + 1 for the next step (in flight while the fix-ups below issue)
+      nu0 = ubuf[j];
+      nu1 = ubuf[16 + j];
+    } else {
+      asm volatile("s_nop 1\n\t" HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_PAIR("x2", "y2") HOMMX_PAIR("x3", "y3")
+                       HOMMX_PAIR("x4", "y4") HOMMX_PAIR("x5", "y5") HOMMX_PAIR("x6", "y6") HOMMX_PAIR("x7", "y7")
+                   : [x0] "+v"(a[0][tK][0]), [y0] "+v"(a[0][o][0]), [x1] "+v"(a[0][tK][1]), [y1] "+v"(a[0][o][1]),
+                     [x2] "+v"(a[0][tK][2]), [y2] "+v"(a[0][o][2]), [x3] "+v"(a[0][tK][3]), [y3] "+v"(a[0][o][3]),
+                     [x4] "+v"(a[1][tK][0]), [y4] "+v"(a[1][o][0]), [x5] "+v"(a[1][tK][1]), [y5] "+v"(a[1][o][1]),
+                     [x6] "+v"(a[1][tK][2]), [y6] "+v"(a[1][o][2]), [x7] "+v"(a[1][tK][3]), [y7] "+v"(a[1][o][3])
+                   : [wk] "v"(w[tK]), [wo] "v"(w[o]), [jk] "n"(jK));
+    }
+#undef PI
+#undef XR
+#undef YR
+    // row rule: row K <- broadcast row; (K, K) <- 1/d
+    masked_mov<RowMask<kK>::lo, RowMask<kK>::hi>(a[tK][0][rK], w[0]);
+    masked_mov<RowMask<kK>::lo, RowMask<kK>::hi>(a[tK][1][rK], w[1]);
+    masked_mov<OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[tK][tK][rK], pinv);
+    if constexpr (more) step<K + 1>(a, ubuf, ub, j, bad, nu0, nu1, pn);
+  }
+
+  // a <- a^-1 (every pivot negative).  ubuf: NB doubles of LDS nobody else touches during the sweep.
+  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int& bad) {
+    const unsigned ub = lds_offset(ubuf) + 8u * (unsigned)j;
+    masked_lds_store2<RowMask<0>::lo, RowMask<0>::hi>(ub, a[0][0][0], ub + 128, a[0][1][0]);
+    int b = 0;
+    const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
+    const double u0 = ubuf[j], u1 = ubuf[16 + j];
+    step<0>(a, ubuf, ub, j, b, u0, u1, fast_rcp(d0));
+    bad |= b;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NB = 16: one tile, 4 registers per lane
+// ---------------------------------------------------------------------------------------------------------------------
+template <>
+struct Sweep<16> {
+  static constexpr int NB = 16, NT = 1;
+  typedef double Mat[1][1][4];
+
+  template <int K>
+  static __device__ __forceinline__ void step(Mat& a, const double* ubuf, unsigned ub, int j, int& bad, double u0, double pinv) {
+    constexpr int jK = K, rK = K / 4, kK = K % 4;
+    constexpr bool more = K + 1 < NB;
+    constexpr int K1 = more ? K + 1 : K;
+    constexpr int jK1 = K1, rK1 = K1 / 4, kK1 = K1 % 4;
+#define PI(i) ((i) < rK1 ? (i) : (i) + 1)
+    double w = u0 * -pinv;
+    masked_mov<ColMask<jK>::lo, ColMask<jK>::hi>(w, pinv - 1.0);
+    double nu0 = 0.0, pn = 1.0;
+    if constexpr (more) {
+      asm volatile("s_nop 1\n\t" HOMMX_ONE("x") : [x] "+v"(a[0][0][rK1]) : [wk] "v"(w), [jk] "n"(jK));
+      masked_lds_store<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[0][0][rK1]);
+      const double dn = readlane_neg_pivot(a[0][0][rK1], 16 * kK1 + jK1, bad);
+      double e;
+      asm volatile("s_nop 1\n\t" HOMMX_RCP0 HOMMX_ONE("x0") HOMMX_RCPE HOMMX_ONE("x1") HOMMX_RCPR HOMMX_ONE("x2") HOMMX_RCPE
+                       HOMMX_RCPR
+                   : [x0] "+v"(a[0][0][PI(0)]), [x1] "+v"(a[0][0][PI(1)]), [x2] "+v"(a[0][0][PI(2)]), [r] "=&v"(pn), [e] "=&v"(e)
+                   : [wk] "v"(w), [d] "s"(dn), [jk] "n"(jK));
+      nu0 = ubuf[j];
+    } else {
+      asm volatile("s_nop 1\n\t" HOMMX_ONE("x0") HOMMX_ONE("x1") HOMMX_ONE("x2") HOMMX_ONE("x3")
+                   : [x0] "+v"(a[0][0][0]), [x1] "+v"(a[0][0][1]), [x2] "+v"(a[0][0][2]), [x3] "+v"(a[0][0][3])
+                   : [wk] "v"(w), [jk] "n"(jK));
+    }
+#undef PI
+    masked_mov<RowMask<kK>::lo, RowMask<kK>::hi>(a[0][0][rK], w);
+    masked_mov<OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[0][0][rK], pinv);
+    if constexpr (more) step<K + 1>(a, ubuf, ub, j, bad, nu0, pn);
+  }
+
+  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int& bad) {
+    const unsigned ub = lds_offset(ubuf) + 8u * (unsigned)j;
+    masked_lds_store<RowMask<0>::lo, RowMask<0>::hi>(ub, a[0][0][0]);
+    int b = 0;
+    const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
+    const double u0 = ubuf[j];
+    step<0>(a, ubuf, ub, j, b, u0, fast_rcp(d0));
+    bad |= b;
+  }
+};
+
+}  // namespace accl
+}  // namespace hommx
