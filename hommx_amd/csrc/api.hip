@@ -58,6 +58,7 @@ struct hommx_plan {
   // host-pointer entry point of the fused family: coefficient chunks stream in on s_copy while s_comp solves the previous one
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
+  bool h2d_overlap = true;  // HOMMX_NO_H2D_OVERLAP (dev knob, read when the plan is created) switches the pipelining off
 };
 
 extern "C" {
@@ -93,6 +94,7 @@ int hommx_plan_create(hommx_plan** out, const hommx_plan_desc* d) {
     case HOMMX_KIND_ELASTICITY_ISO: p->n_comp = 2; p->t = te; break;
     default: p->n_comp = te * (te + 1) / 2; p->t = te; break;
   }
+  p->h2d_overlap = getenv("HOMMX_NO_H2D_OVERLAP") == nullptr;
   p->family = (dim == 2 && d->kind == HOMMX_KIND_POISSON_SCALAR && n <= 32 && !(d->flags & 1)) ? FAM_FUSED2D : FAM_BLOCKED;
   if (p->family == FAM_BLOCKED) {
     int rc = hommx::blocked_workspace_create(&p->ws, dim, n, d->kind);
@@ -173,7 +175,7 @@ int hommx_solve_batch(hommx_plan* p, int64_t n_cells, const double* coef, const 
   if (M) HIP_TRY(hipMemcpy(p->d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
   const int64_t per = p->n_el * p->n_comp;
   constexpr int64_t CH = 2048;  // cells per chunk: one wave per cell fills the 256 CUs x 8 wave slots exactly once
-  if (p->family == FAM_FUSED2D && n_cells >= 2 * CH && !getenv("HOMMX_NO_H2D_OVERLAP")) {
+  if (p->family == FAM_FUSED2D && n_cells >= 2 * CH && p->h2d_overlap) {
     // The coefficient stream (16 KiB per cell) costs more PCIe time than the kernel costs GPU time: pipeline it.  The
     // copies are issued from pageable memory, so each blocks this thread -- while the kernel of the previous chunk,
     // already queued on the other stream, runs.

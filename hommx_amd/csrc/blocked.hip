@@ -801,6 +801,11 @@ hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_
 // ---------------------------------------------------------------------------------------------------------------
 struct BlockedWorkspace {
   Geo G;
+  // development knobs, read ONCE when the plan is created (include/hommx_hip.h lists them)
+  double budget_gb_env = 0.0;  // HOMMX_BLOCKED_MEM_GB (0: automatic)
+  int gemm128_min = 256;       // HOMMX_GEMM128_MIN
+  bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
+  bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
   long long chunk = 0;
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
   double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
@@ -872,6 +877,10 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   G.ncode = dim == 2 ? 9 : 27;
   G.n_el = G.nsub * G.nn;
   fill_tables(G);
+  if (const char* e = getenv("HOMMX_BLOCKED_MEM_GB")) ws->budget_gb_env = atof(e);
+  if (const char* e = getenv("HOMMX_GEMM128_MIN")) ws->gemm128_min = atoi(e);
+  ws->sparse_v1 = getenv("HOMMX_SPARSE_V1") != nullptr;
+  ws->leaf32 = getenv("HOMMX_LEAF32") != nullptr;
   *out = ws;
   return 0;
 }
@@ -919,7 +928,7 @@ static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget_gb = std::min(budget_gb, 0.5e-9 * (double)fr);
   }
-  if (const char* e = getenv("HOMMX_BLOCKED_MEM_GB")) budget_gb = atof(e);
+  if (ws->budget_gb_env > 0.0) budget_gb = ws->budget_gb_env;
   const long long hist_bytes = 8ll * (G.n - 1) * (2ll * G.Bp * G.Bp + 16ll * G.Bp) + 8ll * 3 * 16 * G.Bp;
   if (correctors) {
     long long hc = (long long)(budget_gb * 1e9) / (per_cell_bytes(G) + hist_bytes);
@@ -1114,10 +1123,7 @@ inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + b
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
           const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0,
           double* Ct = nullptr) {
-  static const int min128 = [] {  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
-    const char* e = getenv("HOMMX_GEMM128_MIN");
-    return e ? atoi(e) : 256;
-  }();
+  const int min128 = c.ws->gemm128_min;  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
   const bool big = M >= min128 && N >= min128;
   const int TM = big ? 128 : 64;
   const int tx = (N + TM - 1) / TM, ty = (M + TM - 1) / TM;
@@ -1150,7 +1156,7 @@ void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int r
   dim3 grid((nodes + 255) / 256, (nrows + RT - 1) / RT, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
   const int codeOff = (olast + 1) * (G.ncode / 3);
-  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !getenv("HOMMX_SPARSE_V1")) {  // strip kernel (HOMMX_SPARSE_V1: dev knob, generic kernels)
+  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !c.ws->sparse_v1) {  // strip kernel (HOMMX_SPARSE_V1: dev knob, generic kernels)
     int rpb = (nrows + 31) / 32 * 32;  // rows per workgroup: as many as still leave ~4 workgroups per slot
     while (rpb > 32 && (long long)((nrows + rpb - 1) / rpb) * c.nc * G.n < 4096) rpb = (rpb / 2 + 31) / 32 * 32;
     dim3 g2((unsigned)G.n, (nrows + rpb - 1) / rpb, (unsigned)c.nc);
@@ -1172,7 +1178,7 @@ void left_mult_E(const Ctx& c, const double* X, double* OUT, int rowPlane, doubl
   const Geo& G = c.ws->G;
   dim3 grid((G.Bp + G.bs - 1) / G.bs, 1, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
-  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !getenv("HOMMX_SPARSE_V1")) {  // strip kernel
+  if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !c.ws->sparse_v1) {  // strip kernel
     dim3 g2((unsigned)G.n, 1, (unsigned)c.nc);
     if (G.bs == 1) hipLaunchKernelGGL((k_left_mult_E_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha);
     else hipLaunchKernelGGL((k_left_mult_E_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha);
@@ -1199,7 +1205,7 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
       hipLaunchKernelGGL(k_leaf_inverse<16>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
     return;
   }
-  if (size == 64 && !getenv("HOMMX_LEAF32")) {
+  if (size == 64 && !c.ws->leaf32) {
     hipLaunchKernelGGL(k_leaf_inverse_blk<64>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
     return;
   }

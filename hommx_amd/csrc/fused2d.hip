@@ -467,24 +467,18 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
           using namespace accl;
 #define DIAG_LO(r) (OneLane<0, 4 * (r)>::lo | OneLane<1, 4 * (r) + 1>::lo | OneLane<2, 4 * (r) + 2>::lo | OneLane<3, 4 * (r) + 3>::lo)
 #define DIAG_HI(r) (OneLane<0, 4 * (r)>::hi | OneLane<1, 4 * (r) + 1>::hi | OneLane<2, 4 * (r) + 2>::hi | OneLane<3, 4 * (r) + 3>::hi)
-          masked_sub<DIAG_LO(0), DIAG_HI(0)>(a[t][t][0], dgq[t]);
-          masked_sub<DIAG_LO(1), DIAG_HI(1)>(a[t][t][1], dgq[t]);
-          masked_sub<DIAG_LO(2), DIAG_HI(2)>(a[t][t][2], dgq[t]);
-          masked_sub<DIAG_LO(3), DIAG_HI(3)>(a[t][t][3], dgq[t]);
+          masked_sub4<DIAG_LO(0), DIAG_HI(0), DIAG_LO(1), DIAG_HI(1), DIAG_LO(2), DIAG_HI(2), DIAG_LO(3), DIAG_HI(3)>(
+              a[t][t][0], a[t][t][1], a[t][t][2], a[t][t][3], dgq[t]);
           // sub-diagonal: lanes (j = 4 r + k - 1, k); for r = 0 lane row 0 has no such lane in this tile
 #define SUB_LO(r) (((r) ? OneLane<0, (4 * (r) - 1) & 15>::lo : 0u) | OneLane<1, 4 * (r)>::lo | OneLane<2, 4 * (r) + 1>::lo | OneLane<3, 4 * (r) + 2>::lo)
 #define SUB_HI(r) (((r) ? OneLane<0, (4 * (r) - 1) & 15>::hi : 0u) | OneLane<1, 4 * (r)>::hi | OneLane<2, 4 * (r) + 1>::hi | OneLane<3, 4 * (r) + 2>::hi)
-          masked_sub<SUB_LO(0), SUB_HI(0)>(a[t][t][0], ceq[t]);
-          masked_sub<SUB_LO(1), SUB_HI(1)>(a[t][t][1], ceq[t]);
-          masked_sub<SUB_LO(2), SUB_HI(2)>(a[t][t][2], ceq[t]);
-          masked_sub<SUB_LO(3), SUB_HI(3)>(a[t][t][3], ceq[t]);
+          masked_sub4<SUB_LO(0), SUB_HI(0), SUB_LO(1), SUB_HI(1), SUB_LO(2), SUB_HI(2), SUB_LO(3), SUB_HI(3)>(
+              a[t][t][0], a[t][t][1], a[t][t][2], a[t][t][3], ceq[t]);
           // super-diagonal: lanes (j = 4 r + k + 1, k); for r = 3 lane row 3 has no such lane in this tile
 #define SUP_LO(r) (OneLane<0, 4 * (r) + 1>::lo | OneLane<1, 4 * (r) + 2>::lo | OneLane<2, 4 * (r) + 3>::lo | ((r) < 3 ? OneLane<3, (4 * (r) + 4) & 15>::lo : 0u))
 #define SUP_HI(r) (OneLane<0, 4 * (r) + 1>::hi | OneLane<1, 4 * (r) + 2>::hi | OneLane<2, 4 * (r) + 3>::hi | ((r) < 3 ? OneLane<3, (4 * (r) + 4) & 15>::hi : 0u))
-          masked_sub<SUP_LO(0), SUP_HI(0)>(a[t][t][0], cemq[t]);
-          masked_sub<SUP_LO(1), SUP_HI(1)>(a[t][t][1], cemq[t]);
-          masked_sub<SUP_LO(2), SUP_HI(2)>(a[t][t][2], cemq[t]);
-          masked_sub<SUP_LO(3), SUP_HI(3)>(a[t][t][3], cemq[t]);
+          masked_sub4<SUP_LO(0), SUP_HI(0), SUP_LO(1), SUP_HI(1), SUP_LO(2), SUP_HI(2), SUP_LO(3), SUP_HI(3)>(
+              a[t][t][0], a[t][t][1], a[t][t][2], a[t][t][3], cemq[t]);
 #undef DIAG_LO
 #undef DIAG_HI
 #undef SUB_LO
@@ -562,12 +556,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     {
       using namespace accl;
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) masked_mov<RowMask<3>::lo, RowMask<3>::hi>(a[NT - 1][tj][3], 0.0);
+      for (int tj = 0; tj < NT; ++tj) amov<RowMask<3>::lo, RowMask<3>::hi>(a[NT - 1][tj][3], 0.0);
 #pragma unroll
       for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) masked_mov<ColMask<15>::lo, ColMask<15>::hi>(a[ti][NT - 1][r], 0.0);
-      masked_mov<OneLane<3, 15>::lo, OneLane<3, 15>::hi>(a[NT - 1][NT - 1][3], -1.0);
+        for (int r = 0; r < 4; ++r) amov<ColMask<15>::lo, ColMask<15>::hi>(a[ti][NT - 1][r], 0.0);
+      amov<OneLane<3, 15>::lo, OneLane<3, 15>::hi>(a[NT - 1][NT - 1][3], -1.0);
     }
     if (c == NB - 1) rlm = 0.0;
     __syncthreads();

@@ -44,34 +44,56 @@ template <int K, int J> struct OneLane {
   static constexpr unsigned hi = bit >= 32 ? 1u << (bit & 31) : 0u;
 };
 
-// d += v on the lanes of (LO, HI)
+// Predicated single instructions under a literal exec mask.  These helpers assume EXEC is all ones on entry and leave it
+// all ones: the kernels that use them run ONE full wavefront per workgroup and call them outside any divergent region, so
+// there is nothing to save (one scalar instruction less per use than sweep.h's save / restore form).
+#define HOMMX_EXEC_SET(LO, HI) "s_mov_b32 exec_lo, %[" LO "]\n\ts_mov_b32 exec_hi, %[" HI "]\n\t"
+#define HOMMX_EXEC_ALL "s_mov_b64 exec, -1"
 template <unsigned LO, unsigned HI>
-__device__ __forceinline__ void masked_add(double& d, double v) {
-  unsigned long long sv;
-  asm(HOMMX_EXEC_IN "v_add_f64 %[d], %[d], %[v]\n\t" HOMMX_EXEC_OUT
-      : [d] "+v"(d), [sv] "=&s"(sv) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
+__device__ __forceinline__ void amov(double& d, double v) {
+  asm(HOMMX_EXEC_SET("lo", "hi") "v_mov_b64 %[d], %[v]\n\t" HOMMX_EXEC_ALL : [d] "+v"(d) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
 }
 // d -= v on the lanes of (LO, HI)
 template <unsigned LO, unsigned HI>
 __device__ __forceinline__ void masked_sub(double& d, double v) {
-  unsigned long long sv;
-  asm(HOMMX_EXEC_IN "v_add_f64 %[d], %[d], -%[v]\n\t" HOMMX_EXEC_OUT
-      : [d] "+v"(d), [sv] "=&s"(sv) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
+  asm(HOMMX_EXEC_SET("lo", "hi") "v_add_f64 %[d], %[d], -%[v]\n\t" HOMMX_EXEC_ALL
+      : [d] "+v"(d) : [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI));
+}
+// d_q -= v on the lanes of mask q, q = 0..3 (four registers, four masks, one exec restore)
+template <unsigned L0, unsigned H0, unsigned L1, unsigned H1, unsigned L2, unsigned H2, unsigned L3, unsigned H3>
+__device__ __forceinline__ void masked_sub4(double& d0, double& d1, double& d2, double& d3, double v) {
+  asm(HOMMX_EXEC_SET("l0", "h0") "v_add_f64 %[d0], %[d0], -%[v]\n\t" HOMMX_EXEC_SET("l1", "h1") "v_add_f64 %[d1], %[d1], -%[v]\n\t"
+      HOMMX_EXEC_SET("l2", "h2") "v_add_f64 %[d2], %[d2], -%[v]\n\t" HOMMX_EXEC_SET("l3", "h3") "v_add_f64 %[d3], %[d3], -%[v]\n\t"
+      HOMMX_EXEC_ALL
+      : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3)
+      : [v] "v"(v), [l0] "i"(L0), [h0] "i"(H0), [l1] "i"(L1), [h1] "i"(H1), [l2] "i"(L2), [h2] "i"(H2), [l3] "i"(L3), [h3] "i"(H3));
 }
 // LDS store of one double by the lanes of (LO, HI); `addr` is the byte offset in LDS.  In-order with the wave's other LDS
 // traffic (the LDS queue of a wave is FIFO); the compiler's lgkmcnt bookkeeping stays conservative-correct around it.
 template <unsigned LO, unsigned HI>
 __device__ __forceinline__ void masked_lds_store(unsigned addr, double v) {
-  unsigned long long sv;
-  asm volatile(HOMMX_EXEC_IN "ds_write_b64 %[a], %[v]\n\t" HOMMX_EXEC_OUT
-               : [sv] "=&s"(sv) : [a] "v"(addr), [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI) : "memory");
+  asm volatile(HOMMX_EXEC_SET("lo", "hi") "ds_write_b64 %[a], %[v]\n\t" HOMMX_EXEC_ALL
+               : : [a] "v"(addr), [v] "v"(v), [lo] "i"(LO), [hi] "i"(HI) : "memory");
 }
 template <unsigned LO, unsigned HI>
 __device__ __forceinline__ void masked_lds_store2(unsigned addr0, double v0, unsigned addr1, double v1) {
-  unsigned long long sv;
-  asm volatile(HOMMX_EXEC_IN "ds_write_b64 %[a0], %[v0]\n\tds_write_b64 %[a1], %[v1]\n\t" HOMMX_EXEC_OUT
-               : [sv] "=&s"(sv) : [a0] "v"(addr0), [v0] "v"(v0), [a1] "v"(addr1), [v1] "v"(v1), [lo] "i"(LO), [hi] "i"(HI)
-               : "memory");
+  asm volatile(HOMMX_EXEC_SET("lo", "hi") "ds_write_b64 %[a0], %[v0]\n\tds_write_b64 %[a1], %[v1]\n\t" HOMMX_EXEC_ALL
+               : : [a0] "v"(addr0), [v0] "v"(v0), [a1] "v"(addr1), [v1] "v"(v1), [lo] "i"(LO), [hi] "i"(HI) : "memory");
+}
+// row rule of the exchange: rows <- broadcast row under the lane-row mask, then (K, K) <- 1/d on its one lane
+template <unsigned RLO, unsigned RHI, unsigned PLO, unsigned PHI>
+__device__ __forceinline__ void row_rule2(double& adiag, double& aoff, double wdiag, double woff, double pinv) {
+  asm(HOMMX_EXEC_SET("rlo", "rhi") "v_mov_b64 %[ad], %[wd]\n\tv_mov_b64 %[ao], %[wo]\n\t" HOMMX_EXEC_SET("plo", "phi")
+      "v_mov_b64 %[ad], %[p]\n\t" HOMMX_EXEC_ALL
+      : [ad] "+v"(adiag), [ao] "+v"(aoff)
+      : [wd] "v"(wdiag), [wo] "v"(woff), [p] "v"(pinv), [rlo] "i"(RLO), [rhi] "i"(RHI), [plo] "i"(PLO), [phi] "i"(PHI));
+}
+template <unsigned RLO, unsigned RHI, unsigned PLO, unsigned PHI>
+__device__ __forceinline__ void row_rule1(double& adiag, double wdiag, double pinv) {
+  asm(HOMMX_EXEC_SET("rlo", "rhi") "v_mov_b64 %[ad], %[wd]\n\t" HOMMX_EXEC_SET("plo", "phi") "v_mov_b64 %[ad], %[p]\n\t"
+      HOMMX_EXEC_ALL
+      : [ad] "+v"(adiag)
+      : [wd] "v"(wdiag), [p] "v"(pinv), [rlo] "i"(RLO), [rhi] "i"(RHI), [plo] "i"(PLO), [phi] "i"(PHI));
 }
 
 // byte offset of a __shared__ object in LDS
@@ -124,7 +146,7 @@ struct Sweep<32> {
     double w[2];
     w[0] = u0 * -pinv;
     w[1] = u1 * -pinv;
-    masked_mov<ColMask<jK>::lo, ColMask<jK>::hi>(w[tK], pinv - 1.0);
+    amov<ColMask<jK>::lo, ColMask<jK>::hi>(w[tK], pinv - 1.0);
     double nu0 = 0.0, nu1 = 0.0, pn = 1.0;
     if constexpr (more) {
       // the registers of pivot row K + 1 first, then publish it (raw) and fetch the next pivot
@@ -132,6 +154,9 @@ struct Sweep<32> {
                    : [x] "+v"(a[tK1][tK][rK1]), [y] "+v"(a[tK1][o][rK1])
                    : [wk] "v"(w[tK]), [wo] "v"(w[o]), [jk] "n"(jK));
       masked_lds_store2<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[tK1][0][rK1], ub + 128, a[tK1][1][rK1]);
+      // raw pivot row K + 1 for the next step: in flight during the bulk of the update below
+      nu0 = ubuf[j];
+      nu1 = ubuf[16 + j];
       const double dn = readlane_neg_pivot(a[tK1][tK1][rK1], 16 * kK1 + jK1, bad);
       double e;
       asm volatile("s_nop 1\n\t" HOMMX_RCP0 HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_RCPE HOMMX_PAIR("x2", "y2")
@@ -141,9 +166,6 @@ struct Sweep<32> {
                      [x3] "+v"(XR(3)), [y3] "+v"(YR(3)), [x4] "+v"(XR(4)), [y4] "+v"(YR(4)), [x5] "+v"(XR(5)), [y5] "+v"(YR(5)),
                      [x6] "+v"(XR(6)), [y6] "+v"(YR(6)), [r] "=&v"(pn), [e] "=&v"(e)
                    : [wk] "v"(w[tK]), [wo] "v"(w[o]), [d] "s"(dn), [jk] "n"(jK));
-      // raw pivot row K + 1 for the next step (in flight while the fix-ups below issue)
-      nu0 = ubuf[j];
-      nu1 = ubuf[16 + j];
     } else {
       asm volatile("s_nop 1\n\t" HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_PAIR("x2", "y2") HOMMX_PAIR("x3", "y3")
                        HOMMX_PAIR("x4", "y4") HOMMX_PAIR("x5", "y5") HOMMX_PAIR("x6", "y6") HOMMX_PAIR("x7", "y7")
@@ -157,9 +179,7 @@ struct Sweep<32> {
 #undef XR
 #undef YR
     // row rule: row K <- broadcast row; (K, K) <- 1/d
-    masked_mov<RowMask<kK>::lo, RowMask<kK>::hi>(a[tK][0][rK], w[0]);
-    masked_mov<RowMask<kK>::lo, RowMask<kK>::hi>(a[tK][1][rK], w[1]);
-    masked_mov<OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[tK][tK][rK], pinv);
+    row_rule2<RowMask<kK>::lo, RowMask<kK>::hi, OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[tK][tK][rK], a[tK][o][rK], w[tK], w[o], pinv);
     if constexpr (more) step<K + 1>(a, ubuf, ub, j, bad, nu0, nu1, pn);
   }
 
@@ -191,26 +211,25 @@ struct Sweep<16> {
     constexpr int jK1 = K1, rK1 = K1 / 4, kK1 = K1 % 4;
 #define PI(i) ((i) < rK1 ? (i) : (i) + 1)
     double w = u0 * -pinv;
-    masked_mov<ColMask<jK>::lo, ColMask<jK>::hi>(w, pinv - 1.0);
+    amov<ColMask<jK>::lo, ColMask<jK>::hi>(w, pinv - 1.0);
     double nu0 = 0.0, pn = 1.0;
     if constexpr (more) {
       asm volatile("s_nop 1\n\t" HOMMX_ONE("x") : [x] "+v"(a[0][0][rK1]) : [wk] "v"(w), [jk] "n"(jK));
       masked_lds_store<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[0][0][rK1]);
+      nu0 = ubuf[j];
       const double dn = readlane_neg_pivot(a[0][0][rK1], 16 * kK1 + jK1, bad);
       double e;
       asm volatile("s_nop 1\n\t" HOMMX_RCP0 HOMMX_ONE("x0") HOMMX_RCPE HOMMX_ONE("x1") HOMMX_RCPR HOMMX_ONE("x2") HOMMX_RCPE
                        HOMMX_RCPR
                    : [x0] "+v"(a[0][0][PI(0)]), [x1] "+v"(a[0][0][PI(1)]), [x2] "+v"(a[0][0][PI(2)]), [r] "=&v"(pn), [e] "=&v"(e)
                    : [wk] "v"(w), [d] "s"(dn), [jk] "n"(jK));
-      nu0 = ubuf[j];
     } else {
       asm volatile("s_nop 1\n\t" HOMMX_ONE("x0") HOMMX_ONE("x1") HOMMX_ONE("x2") HOMMX_ONE("x3")
                    : [x0] "+v"(a[0][0][0]), [x1] "+v"(a[0][0][1]), [x2] "+v"(a[0][0][2]), [x3] "+v"(a[0][0][3])
                    : [wk] "v"(w), [jk] "n"(jK));
     }
 #undef PI
-    masked_mov<RowMask<kK>::lo, RowMask<kK>::hi>(a[0][0][rK], w);
-    masked_mov<OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[0][0][rK], pinv);
+    row_rule1<RowMask<kK>::lo, RowMask<kK>::hi, OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[0][0][rK], w, pinv);
     if constexpr (more) step<K + 1>(a, ubuf, ub, j, bad, nu0, pn);
   }
 

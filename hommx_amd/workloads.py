@@ -62,6 +62,19 @@ def c2_inclusion(nx=64, n=32, x_shift=0.0):
     return msh, coef, None
 
 
+def c2_inclusion_two_phase(nx=64, n=32, x_shift=0.0, cells=None):
+    """C2 as (mesh, mask[n_el], values[N_c, 2]): what ``MicroCellPlan.solve_two_phase`` takes (phase 0 = matrix, 1 = disc).
+    ``cells``: optional index array -- sample only these macro cells (a rank's shard)."""
+    msh = _mesh.create_unit_square(nx, nx)
+    c = msh.cell_midpoints()
+    if cells is not None:
+        c = c[cells]
+    y = element_barycentres(2, n)
+    mask = wrapped_disc(y[:, 0], y[:, 1])
+    values = np.stack([np.full(c.shape[0], 0.1), 0.001 * (1.0 + 9.0 * (c[:, 0] + x_shift))], axis=1)
+    return msh, mask, values
+
+
 def c3_wavy_laminate(nx=128, n=32):
     """C3: PoissonStratifiedHMM, laminate in y1, theta(x) = (x0, x1 - sin 2 pi x0) (README.md:96-99)."""
     msh = _mesh.create_unit_square(nx, nx)
@@ -93,6 +106,51 @@ def fibre_lame(c, n, mu_in):
     return np.stack([lam, mu], axis=-1)
 
 
+def fibre_mask(n):
+    """Phase mask of the fibre (wrapped disc in (y1, y2)) on the 6 n^3 tets of the unit-cell mesh."""
+    y = element_barycentres(3, n)
+    return wrapped_disc(y[:, 1], y[:, 2])
+
+
+def c5_theta_transpose(c):
+    """M[i][j] = d theta_j / d x_i at the points c[N, 3] for theta(x) = (x0, x1, cos(g) x2 - sin(g) x0), g = (pi/2) x1/0.4."""
+    gam = 0.5 * np.pi * c[:, 1] / 0.4
+    dg = 0.5 * np.pi / 0.4
+    Dth = np.zeros((c.shape[0], 3, 3))  # Dth[i][j] = d theta_i / d x_j
+    Dth[:, 0, 0] = 1.0
+    Dth[:, 1, 1] = 1.0
+    Dth[:, 2, 0] = -np.sin(gam)
+    Dth[:, 2, 1] = dg * (-np.sin(gam) * c[:, 2] - np.cos(gam) * c[:, 0])
+    Dth[:, 2, 2] = np.cos(gam)
+    return np.transpose(Dth, (0, 2, 1)).copy()
+
+
+def c4_two_phase(shape=(20, 6, 6), n=16, cells=None):
+    """C4 as (mesh, mask[n_el], values[N_c, 2, 2] = (lambda, mu) of matrix / fibre, None)."""
+    msh = _mesh.create_box([(0, 0, 0), (1.0, 0.4, 0.1)], shape)
+    c = msh.cell_midpoints()
+    if cells is not None:
+        c = c[cells]
+    values = np.empty((c.shape[0], 2, 2))
+    values[:, :, 0] = 1.0
+    values[:, 0, 1] = 0.001
+    values[:, 1, 1] = 100.0 * (1.0 + c[:, 0])
+    return msh, fibre_mask(n), values, None
+
+
+def c5_two_phase(shape=(32, 16, 8), n=16, cells=None):
+    """C5 as (mesh, mask[n_el], values[N_c, 2, 2], M[N_c, 3, 3]); ``cells`` restricts the sampling to a rank's shard."""
+    msh = _mesh.create_box([(0, 0, 0), (1.0, 0.4, 0.1)], shape)
+    c = msh.cell_midpoints()
+    if cells is not None:
+        c = c[cells]
+    values = np.empty((c.shape[0], 2, 2))
+    values[:, :, 0] = 1.0
+    values[:, 0, 1] = 0.001
+    values[:, 1, 1] = 100.0
+    return msh, fibre_mask(n), values, c5_theta_transpose(c)
+
+
 def c4_fibre_beam(shape=(20, 6, 6), n=16):
     """C4: LinearElasticityHMM, beam 1x0.4x0.1, fibre along y0 with mu_in = 100 (1 + x0)."""
     msh = _mesh.create_box([(0, 0, 0), (1.0, 0.4, 0.1)], shape)
@@ -105,13 +163,4 @@ def c5_rotated_fibres(shape=(32, 16, 8), n=16):
     msh = _mesh.create_box([(0, 0, 0), (1.0, 0.4, 0.1)], shape)
     c = msh.cell_midpoints()
     coef = fibre_lame(c, n, np.full(c.shape[0], 100.0))
-    gam = 0.5 * np.pi * c[:, 1] / 0.4
-    dg = 0.5 * np.pi / 0.4
-    Dth = np.zeros((c.shape[0], 3, 3))  # Dth[i][j] = d theta_i / d x_j
-    Dth[:, 0, 0] = 1.0
-    Dth[:, 1, 1] = 1.0
-    Dth[:, 2, 0] = -np.sin(gam)
-    Dth[:, 2, 1] = dg * (-np.sin(gam) * c[:, 2] - np.cos(gam) * c[:, 0])
-    Dth[:, 2, 2] = np.cos(gam)
-    M = np.transpose(Dth, (0, 2, 1)).copy()  # M[i][j] = d theta_j / d x_i (hmm.py:741)
-    return msh, coef, M
+    return msh, coef, c5_theta_transpose(c)  # M[i][j] = d theta_j / d x_i (hmm.py:741)

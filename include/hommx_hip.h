@@ -41,10 +41,12 @@ extern "C" {
 
 #define HOMMX_FLAG_FORCE_BLOCKED 1     /* use the generic blocked kernel family even where the fused 2D kernel applies */
 
-/* Environment knobs (development / tuning; read once per process):
+/* Environment knobs (development / tuning; read once, when a plan is created):
  *   HOMMX_BLOCKED_MEM_GB   workspace budget of the blocked family in GB (default min(64, half of the free HBM))
  *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256)
- *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products                              */
+ *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products
+ *   HOMMX_LEAF32           any value: 32x32 leaves only in the recursive block inverse
+ *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel        */
 
 typedef struct hommx_plan hommx_plan;
 

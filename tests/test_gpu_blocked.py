@@ -5,6 +5,7 @@ Tolerance 1e-9 relative per cell tensor (float64; observed 1e-15..1e-12); high-c
 
 import glob
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -32,7 +33,7 @@ def plan(dim, n, kind, flags=0):
 
 
 def test_all_golden_vectors():
-    files = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    files = sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith("fullsize_"))
     assert len(files) == 10
     for f in files:
         g = np.load(f)
@@ -128,6 +129,65 @@ def test_c4_c5_reduced_vs_oracle(O):
     got, info = plan(3, 8, "elasticity").solve(coef, M, return_info=True)
     assert np.all(info == 0)
     assert relerr(got, O.effective_tensor_batch("elasticity", 3, 8, coef, M)) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["c4_n16", "c5_n16_strat"])
+def test_full_size_golden_cells_default_plan(name):
+    """Production size (16^3 micro cells, 12288 unknowns, Bp = 768: the 128x128 GEMM tiles and the strip-form sparse products)
+    through the DEFAULT plan -- no flags, default HOMMX_GEMM128_MIN -- against oracle tensors of three cells of C4 / C5
+    (lowest / middle / highest fibre contrast; most / half / least rotated M).  Forms hmm.py:887-922 / 1024-1067, coefficient
+    rotated_fibers.py:23-76.  Fixtures: tests/golden/fullsize_*.npz, made by tests/golden/make_golden.py (oracle, ~25 s per cell)."""
+    sys.path.insert(0, GOLDEN)
+    from make_golden import expand_fibre_fixture
+
+    g = np.load(os.path.join(GOLDEN, f"fullsize_{name}.npz"))
+    coef = expand_fibre_fixture(g)
+    assert coef.shape == (3, 24576, 2)
+    M = g["M"] if g["M"].size else None
+    p = plan(3, 16, "elasticity")
+    assert p.kernel == "blocked"
+    C, info = p.solve(coef, M, return_info=True)
+    assert np.all(info == 0)
+    assert relerr(C, g["A_eff"]) < 1e-7, relerr(C, g["A_eff"])
+    # the same cells through the two-phase entry point (mask + two (lambda, mu) pairs per cell): bit-identical
+    mask = np.unpackbits(g["mask_bits"])[: 24576]
+    C2 = p.solve_two_phase(mask, g["values"], M)
+    assert np.array_equal(C, C2)
+
+
+def test_c5_full_size_chunked_properties():
+    """C5 at production size on a subset that spans several workspace chunks (HOMMX_BLOCKED_MEM_GB is read once per process, so
+    the small budget is set in a child process): chunking must not change a single bit, tensors are symmetric positive
+    definite, and the fixture cells come out as in the one-chunk run."""
+    import subprocess, textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {root!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan, workloads as W
+        msh, coef, M = W.c5_rotated_fibres(shape=(8, 4, 2))      # 384 tets of the C5 family, same theta, same fibre
+        sel = np.arange(0, 384, 3)[:100]
+        p = MicroCellPlan(3, 16, "elasticity")
+        C, info = p.solve(coef[sel], M[sel], return_info=True)
+        assert not info.any()
+        np.save(sys.argv[1], C)
+        print("ok")
+    """)
+    outs = []
+    for tag, gb in (("small", "1.5"), ("default", None)):
+        env = dict(os.environ)
+        if gb:
+            env["HOMMX_BLOCKED_MEM_GB"] = gb  # 36 MB per cell => about 40 cells per chunk: 3 chunks for 100 cells
+        f = os.path.join("/tmp", f"hommx_c5_chunk_{tag}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+        outs.append(np.load(f))
+        os.remove(f)
+    a, b = outs
+    assert np.array_equal(a, b)
+    assert np.abs(a - np.transpose(a, (0, 2, 1))).max() < 1e-9 * np.abs(a).max()
+    assert np.all(np.linalg.eigvalsh(0.5 * (a + np.transpose(a, (0, 2, 1)))) > 0)
 
 
 def test_c4_full_size_properties():
