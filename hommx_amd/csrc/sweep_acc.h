@@ -115,10 +115,12 @@ __device__ __forceinline__ double readlane_neg_pivot(double v, int lane, int& ba
 // y += bcast(x) * wo ; x += bcast(x) * wk   (x = register of the pivot's column tile, y = the other column tile)
 #define HOMMX_PAIR(X, Y) "v_fmac_f64_dpp %[" Y "], %[" X "], %[wo]" HOMMX_BC "v_fmac_f64_dpp %[" X "], %[" X "], %[wk]" HOMMX_BC
 #define HOMMX_ONE(X) "v_fmac_f64_dpp %[" X "], %[" X "], %[wk]" HOMMX_BC
-// reciprocal of the NEXT pivot interleaved with the updates: v_rcp_f64 + two Newton steps
+// reciprocal of the NEXT pivot interleaved with the updates: v_rcp_f64 (2^-24.4 on gfx950, tools/probe_rcp64.hip) and ONE
+// third-order step  e = 1 - d r;  r <- r + r (e + e^2)  (error e^3: 1 ulp, one instruction less than two Newton steps)
 #define HOMMX_RCP0 "v_rcp_f64 %[r], %[d]\n\t"
 #define HOMMX_RCPE "v_fma_f64 %[e], -%[d], %[r], 1.0\n\t"
-#define HOMMX_RCPR "v_fma_f64 %[r], %[e], %[r], %[r]\n\t"
+#define HOMMX_RCPT "v_fma_f64 %[e], %[e], %[e], %[e]\n\t"
+#define HOMMX_RCPR "v_fma_f64 %[r], %[r], %[e], %[r]\n\t"
 
 template <int NB> struct Sweep;
 
@@ -132,7 +134,7 @@ struct Sweep<32> {
 
   // ubuf: LDS, NB doubles, [tj][j]; ub = byte offset of ubuf + 8 j (per lane)
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, const double* ubuf, unsigned ub, int j, int& bad, double u0, double u1,
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, unsigned ub, int j, int& bad, double u0, double u1,
                                               double pinv) {
     constexpr int tK = K / 16, jK = K % 16, rK = (K % 16) / 4, kK = K % 4, o = 1 - tK;
     constexpr bool more = K + 1 < NB;
@@ -142,11 +144,11 @@ struct Sweep<32> {
 #define PI(i) ((i) < E ? (i) : (i) + 1)
 #define XR(i) a[PI(i) / 4][tK][PI(i) % 4]
 #define YR(i) a[PI(i) / 4][o][PI(i) % 4]
-    // broadcast row: w = -u / d; entry K becomes 1/d - 1 (column rule)
+    // broadcast row: w = -u / d.  Its entry K arrives as d - 1 (the publisher overwrote that slot), so w[K] = 1/d - 1: the
+    // column rule rides on the rank-1 update
     double w[2];
     w[0] = u0 * -pinv;
     w[1] = u1 * -pinv;
-    amov<ColMask<jK>::lo, ColMask<jK>::hi>(w[tK], pinv - 1.0);
     double nu0 = 0.0, nu1 = 0.0, pn = 1.0;
     if constexpr (more) {
       // the registers of pivot row K + 1 first, then publish it (raw) and fetch the next pivot
@@ -154,13 +156,14 @@ struct Sweep<32> {
                    : [x] "+v"(a[tK1][tK][rK1]), [y] "+v"(a[tK1][o][rK1])
                    : [wk] "v"(w[tK]), [wo] "v"(w[o]), [jk] "n"(jK));
       masked_lds_store2<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[tK1][0][rK1], ub + 128, a[tK1][1][rK1]);
+      const double dn = readlane_neg_pivot(a[tK1][tK1][rK1], 16 * kK1 + jK1, bad);
+      ubuf[K1] = dn - 1.0;  // every lane stores the same value: slot K + 1 <- d - 1
       // raw pivot row K + 1 for the next step: in flight during the bulk of the update below
       nu0 = ubuf[j];
       nu1 = ubuf[16 + j];
-      const double dn = readlane_neg_pivot(a[tK1][tK1][rK1], 16 * kK1 + jK1, bad);
       double e;
-      asm volatile("s_nop 1\n\t" HOMMX_RCP0 HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_RCPE HOMMX_PAIR("x2", "y2")
-                       HOMMX_RCPR HOMMX_PAIR("x3", "y3") HOMMX_RCPE HOMMX_PAIR("x4", "y4") HOMMX_RCPR HOMMX_PAIR("x5", "y5")
+      asm volatile(HOMMX_RCP0 HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_RCPE HOMMX_PAIR("x2", "y2")
+                       HOMMX_PAIR("x3", "y3") HOMMX_RCPT HOMMX_PAIR("x4", "y4") HOMMX_PAIR("x5", "y5") HOMMX_RCPR
                            HOMMX_PAIR("x6", "y6")
                    : [x0] "+v"(XR(0)), [y0] "+v"(YR(0)), [x1] "+v"(XR(1)), [y1] "+v"(YR(1)), [x2] "+v"(XR(2)), [y2] "+v"(YR(2)),
                      [x3] "+v"(XR(3)), [y3] "+v"(YR(3)), [x4] "+v"(XR(4)), [y4] "+v"(YR(4)), [x5] "+v"(XR(5)), [y5] "+v"(YR(5)),
@@ -189,6 +192,7 @@ struct Sweep<32> {
     masked_lds_store2<RowMask<0>::lo, RowMask<0>::hi>(ub, a[0][0][0], ub + 128, a[0][1][0]);
     int b = 0;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
+    ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j], u1 = ubuf[16 + j];
     step<0>(a, ubuf, ub, j, b, u0, u1, fast_rcp(d0));
     bad |= b;
@@ -204,23 +208,22 @@ struct Sweep<16> {
   typedef double Mat[1][1][4];
 
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, const double* ubuf, unsigned ub, int j, int& bad, double u0, double pinv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, unsigned ub, int j, int& bad, double u0, double pinv) {
     constexpr int jK = K, rK = K / 4, kK = K % 4;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
     constexpr int jK1 = K1, rK1 = K1 / 4, kK1 = K1 % 4;
 #define PI(i) ((i) < rK1 ? (i) : (i) + 1)
-    double w = u0 * -pinv;
-    amov<ColMask<jK>::lo, ColMask<jK>::hi>(w, pinv - 1.0);
+    const double w = u0 * -pinv;  // entry K arrives as d - 1: w[K] = 1/d - 1 (column rule)
     double nu0 = 0.0, pn = 1.0;
     if constexpr (more) {
       asm volatile("s_nop 1\n\t" HOMMX_ONE("x") : [x] "+v"(a[0][0][rK1]) : [wk] "v"(w), [jk] "n"(jK));
       masked_lds_store<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[0][0][rK1]);
-      nu0 = ubuf[j];
       const double dn = readlane_neg_pivot(a[0][0][rK1], 16 * kK1 + jK1, bad);
+      ubuf[K1] = dn - 1.0;
+      nu0 = ubuf[j];
       double e;
-      asm volatile("s_nop 1\n\t" HOMMX_RCP0 HOMMX_ONE("x0") HOMMX_RCPE HOMMX_ONE("x1") HOMMX_RCPR HOMMX_ONE("x2") HOMMX_RCPE
-                       HOMMX_RCPR
+      asm volatile(HOMMX_RCP0 HOMMX_ONE("x0") HOMMX_RCPE HOMMX_ONE("x1") HOMMX_RCPT HOMMX_ONE("x2") HOMMX_RCPR
                    : [x0] "+v"(a[0][0][PI(0)]), [x1] "+v"(a[0][0][PI(1)]), [x2] "+v"(a[0][0][PI(2)]), [r] "=&v"(pn), [e] "=&v"(e)
                    : [wk] "v"(w), [d] "s"(dn), [jk] "n"(jK));
     } else {
@@ -238,6 +241,7 @@ struct Sweep<16> {
     masked_lds_store<RowMask<0>::lo, RowMask<0>::hi>(ub, a[0][0][0]);
     int b = 0;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
+    ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j];
     step<0>(a, ubuf, ub, j, b, u0, fast_rcp(d0));
     bad |= b;
