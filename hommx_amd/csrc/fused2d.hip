@@ -61,7 +61,7 @@ constexpr int MATP = 48;
 template <int NB>
 struct alignas(16) Lds {
   double mat[(NB + 1) * MATP];
-  double ubuf[NB];      // sweep: raw pivot row, [tj][j]
+  double ubuf[4 * NB];  // sweep: raw pivot rows, one buffer per lane row: [k][tj][j]
   double rrow[2][NB];   // R of the current block, row layout: [m][(i & 3) * KK + (i >> 2)]
   double vrow[2][NB];   // Vr' = R N, row layout
   double vnat[2][NB];   // Vr', natural order
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     // (1) N = T^-1
     {
       int badj = 0;
-      accl::Sweep<NB>::run(a, L.ubuf, j, badj);
+      accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
       if (badj && !bad) { bad = 1; badstep = jr + 1; }
     }
 #ifdef HOMMX_FUSED_DEBUG
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     L.vnat[k >> 1][c] = rlm;  // natural copy of R_last (vnat is free now)
     __syncthreads();
     int badj = 0;
-    accl::Sweep<NB>::run(a, L.ubuf, j, badj);
+    accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
     if (badj && !bad) { bad = 1; badstep = n; }
     double part[2][NT];
 #pragma unroll

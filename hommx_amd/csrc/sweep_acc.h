@@ -80,20 +80,30 @@ __device__ __forceinline__ void masked_lds_store2(unsigned addr0, double v0, uns
   asm volatile(HOMMX_EXEC_SET("lo", "hi") "ds_write_b64 %[a0], %[v0]\n\tds_write_b64 %[a1], %[v1]\n\t" HOMMX_EXEC_ALL
                : : [a0] "v"(addr0), [v0] "v"(v0), [a1] "v"(addr1), [v1] "v"(v1), [lo] "i"(LO), [hi] "i"(HI) : "memory");
 }
-// row rule of the exchange: rows <- broadcast row under the lane-row mask, then (K, K) <- 1/d on its one lane
-template <unsigned RLO, unsigned RHI, unsigned PLO, unsigned PHI>
-__device__ __forceinline__ void row_rule2(double& adiag, double& aoff, double wdiag, double woff, double pinv) {
-  asm(HOMMX_EXEC_SET("rlo", "rhi") "v_mov_b64 %[ad], %[wd]\n\tv_mov_b64 %[ao], %[wo]\n\t" HOMMX_EXEC_SET("plo", "phi")
-      "v_mov_b64 %[ad], %[p]\n\t" HOMMX_EXEC_ALL
-      : [ad] "+v"(adiag), [ao] "+v"(aoff)
-      : [wd] "v"(wdiag), [wo] "v"(woff), [p] "v"(pinv), [rlo] "i"(RLO), [rhi] "i"(RHI), [plo] "i"(PLO), [phi] "i"(PHI));
+// row rule of the exchange: row K <- broadcast row, under the lane-row mask.  The broadcast row carries 1/d - 1 at entry K where
+// the exchange wants 1/d; nothing reads a pivoted diagonal entry again during the sweep (later pivots only add to it), so the
+// missing "+ 1" of all NB diagonal entries is added once at the end (diag_plus_one): 2 masked moves per pivot instead of 3.
+template <unsigned RLO, unsigned RHI>
+__device__ __forceinline__ void row_rule2(double& a0, double& a1, double w0, double w1) {
+  asm(HOMMX_EXEC_SET("rlo", "rhi") "v_mov_b64 %[a0], %[w0]\n\tv_mov_b64 %[a1], %[w1]\n\t" HOMMX_EXEC_ALL
+      : [a0] "+v"(a0), [a1] "+v"(a1) : [w0] "v"(w0), [w1] "v"(w1), [rlo] "i"(RLO), [rhi] "i"(RHI));
 }
-template <unsigned RLO, unsigned RHI, unsigned PLO, unsigned PHI>
-__device__ __forceinline__ void row_rule1(double& adiag, double wdiag, double pinv) {
-  asm(HOMMX_EXEC_SET("rlo", "rhi") "v_mov_b64 %[ad], %[wd]\n\t" HOMMX_EXEC_SET("plo", "phi") "v_mov_b64 %[ad], %[p]\n\t"
+template <unsigned RLO, unsigned RHI>
+__device__ __forceinline__ void row_rule1(double& a0, double w0) {
+  asm(HOMMX_EXEC_SET("rlo", "rhi") "v_mov_b64 %[a0], %[w0]\n\t" HOMMX_EXEC_ALL : [a0] "+v"(a0) : [w0] "v"(w0), [rlo] "i"(RLO), [rhi] "i"(RHI));
+}
+// diagonal of a diagonal tile: register r holds it on the lanes (j = 4 r + k, k)
+template <int R> struct DiagMask {
+  static constexpr unsigned lo = OneLane<0, 4 * R>::lo | OneLane<1, 4 * R + 1>::lo | OneLane<2, 4 * R + 2>::lo | OneLane<3, 4 * R + 3>::lo;
+  static constexpr unsigned hi = OneLane<0, 4 * R>::hi | OneLane<1, 4 * R + 1>::hi | OneLane<2, 4 * R + 2>::hi | OneLane<3, 4 * R + 3>::hi;
+};
+__device__ __forceinline__ void diag_plus_one(double& d0, double& d1, double& d2, double& d3) {
+  asm(HOMMX_EXEC_SET("l0", "h0") "v_add_f64 %[d0], %[d0], 1.0\n\t" HOMMX_EXEC_SET("l1", "h1") "v_add_f64 %[d1], %[d1], 1.0\n\t"
+      HOMMX_EXEC_SET("l2", "h2") "v_add_f64 %[d2], %[d2], 1.0\n\t" HOMMX_EXEC_SET("l3", "h3") "v_add_f64 %[d3], %[d3], 1.0\n\t"
       HOMMX_EXEC_ALL
-      : [ad] "+v"(adiag)
-      : [wd] "v"(wdiag), [p] "v"(pinv), [rlo] "i"(RLO), [rhi] "i"(RHI), [plo] "i"(PLO), [phi] "i"(PHI));
+      : [d0] "+v"(d0), [d1] "+v"(d1), [d2] "+v"(d2), [d3] "+v"(d3)
+      : [l0] "i"(DiagMask<0>::lo), [h0] "i"(DiagMask<0>::hi), [l1] "i"(DiagMask<1>::lo), [h1] "i"(DiagMask<1>::hi),
+        [l2] "i"(DiagMask<2>::lo), [h2] "i"(DiagMask<2>::hi), [l3] "i"(DiagMask<3>::lo), [h3] "i"(DiagMask<3>::hi));
 }
 
 // byte offset of a __shared__ object in LDS
@@ -132,10 +142,9 @@ struct Sweep<32> {
   static constexpr int NB = 32, NT = 2;
   typedef double Mat[2][2][4];
 
-  // ubuf: LDS, NB doubles, [tj][j]; ub = byte offset of ubuf + 8 j (per lane)
+  // ubuf: LDS, 4 row buffers of NB doubles ([lane row][tj][j]); lk = NB * (lane row of this lane)
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, double* ubuf, unsigned ub, int j, int& bad, double u0, double u1,
-                                              double pinv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double u1, double pinv) {
     constexpr int tK = K / 16, jK = K % 16, rK = (K % 16) / 4, kK = K % 4, o = 1 - tK;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
@@ -155,12 +164,16 @@ struct Sweep<32> {
       asm volatile("s_nop 1\n\t" HOMMX_PAIR("x", "y")
                    : [x] "+v"(a[tK1][tK][rK1]), [y] "+v"(a[tK1][o][rK1])
                    : [wk] "v"(w[tK]), [wo] "v"(w[o]), [jk] "n"(jK));
-      masked_lds_store2<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[tK1][0][rK1], ub + 128, a[tK1][1][rK1]);
+      // publish: every lane row stores its row of these registers into ITS OWN copy of the row buffer (no exec change);
+      // copy kK1 is pivot row K + 1
+      ubuf[lk + j] = a[tK1][0][rK1];
+      ubuf[lk + 16 + j] = a[tK1][1][rK1];
       const double dn = readlane_neg_pivot(a[tK1][tK1][rK1], 16 * kK1 + jK1, bad);
-      ubuf[K1] = dn - 1.0;  // every lane stores the same value: slot K + 1 <- d - 1
+      ubuf[NB * kK1 + K1] = dn - 1.0;  // every lane stores the same value: slot K + 1 <- d - 1
       // raw pivot row K + 1 for the next step: in flight during the bulk of the update below
-      nu0 = ubuf[j];
-      nu1 = ubuf[16 + j];
+      nu0 = ubuf[NB * kK1 + j];
+      nu1 = ubuf[NB * kK1 + 16 + j];
+      asm volatile("" ::: "memory");  // keep the loads in front of the update block
       double e;
       asm volatile(HOMMX_RCP0 HOMMX_PAIR("x0", "y0") HOMMX_PAIR("x1", "y1") HOMMX_RCPE HOMMX_PAIR("x2", "y2")
                        HOMMX_PAIR("x3", "y3") HOMMX_RCPT HOMMX_PAIR("x4", "y4") HOMMX_PAIR("x5", "y5") HOMMX_RCPR
@@ -182,19 +195,22 @@ struct Sweep<32> {
 #undef XR
 #undef YR
     // row rule: row K <- broadcast row; (K, K) <- 1/d
-    row_rule2<RowMask<kK>::lo, RowMask<kK>::hi, OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[tK][tK][rK], a[tK][o][rK], w[tK], w[o], pinv);
-    if constexpr (more) step<K + 1>(a, ubuf, ub, j, bad, nu0, nu1, pn);
+    row_rule2<RowMask<kK>::lo, RowMask<kK>::hi>(a[tK][0][rK], a[tK][1][rK], w[0], w[1]);
+    if constexpr (more) step<K + 1>(a, ubuf, lk, j, bad, nu0, nu1, pn);
   }
 
-  // a <- a^-1 (every pivot negative).  ubuf: NB doubles of LDS nobody else touches during the sweep.
-  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int& bad) {
-    const unsigned ub = lds_offset(ubuf) + 8u * (unsigned)j;
-    masked_lds_store2<RowMask<0>::lo, RowMask<0>::hi>(ub, a[0][0][0], ub + 128, a[0][1][0]);
+  // a <- a^-1 (every pivot negative).  ubuf: 4 NB doubles of LDS nobody else touches during the sweep (one row buffer per lane row).
+  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad) {
+    const int lk = NB * k;
+    ubuf[lk + j] = a[0][0][0];
+    ubuf[lk + 16 + j] = a[0][1][0];
     int b = 0;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
     ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j], u1 = ubuf[16 + j];
-    step<0>(a, ubuf, ub, j, b, u0, u1, fast_rcp(d0));
+    step<0>(a, ubuf, lk, j, b, u0, u1, fast_rcp(d0));
+    diag_plus_one(a[0][0][0], a[0][0][1], a[0][0][2], a[0][0][3]);
+    diag_plus_one(a[1][1][0], a[1][1][1], a[1][1][2], a[1][1][3]);
     bad |= b;
   }
 };
@@ -208,7 +224,7 @@ struct Sweep<16> {
   typedef double Mat[1][1][4];
 
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, double* ubuf, unsigned ub, int j, int& bad, double u0, double pinv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double pinv) {
     constexpr int jK = K, rK = K / 4, kK = K % 4;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
@@ -218,10 +234,11 @@ struct Sweep<16> {
     double nu0 = 0.0, pn = 1.0;
     if constexpr (more) {
       asm volatile("s_nop 1\n\t" HOMMX_ONE("x") : [x] "+v"(a[0][0][rK1]) : [wk] "v"(w), [jk] "n"(jK));
-      masked_lds_store<RowMask<kK1>::lo, RowMask<kK1>::hi>(ub, a[0][0][rK1]);
+      ubuf[lk + j] = a[0][0][rK1];
       const double dn = readlane_neg_pivot(a[0][0][rK1], 16 * kK1 + jK1, bad);
-      ubuf[K1] = dn - 1.0;
-      nu0 = ubuf[j];
+      ubuf[NB * kK1 + K1] = dn - 1.0;
+      nu0 = ubuf[NB * kK1 + j];
+      asm volatile("" ::: "memory");
       double e;
       asm volatile(HOMMX_RCP0 HOMMX_ONE("x0") HOMMX_RCPE HOMMX_ONE("x1") HOMMX_RCPT HOMMX_ONE("x2") HOMMX_RCPR
                    : [x0] "+v"(a[0][0][PI(0)]), [x1] "+v"(a[0][0][PI(1)]), [x2] "+v"(a[0][0][PI(2)]), [r] "=&v"(pn), [e] "=&v"(e)
@@ -232,18 +249,19 @@ struct Sweep<16> {
                    : [wk] "v"(w), [jk] "n"(jK));
     }
 #undef PI
-    row_rule1<RowMask<kK>::lo, RowMask<kK>::hi, OneLane<kK, jK>::lo, OneLane<kK, jK>::hi>(a[0][0][rK], w, pinv);
-    if constexpr (more) step<K + 1>(a, ubuf, ub, j, bad, nu0, pn);
+    row_rule1<RowMask<kK>::lo, RowMask<kK>::hi>(a[0][0][rK], w);
+    if constexpr (more) step<K + 1>(a, ubuf, lk, j, bad, nu0, pn);
   }
 
-  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int& bad) {
-    const unsigned ub = lds_offset(ubuf) + 8u * (unsigned)j;
-    masked_lds_store<RowMask<0>::lo, RowMask<0>::hi>(ub, a[0][0][0]);
+  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad) {
+    const int lk = NB * k;
+    ubuf[lk + j] = a[0][0][0];
     int b = 0;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
     ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j];
-    step<0>(a, ubuf, ub, j, b, u0, fast_rcp(d0));
+    step<0>(a, ubuf, lk, j, b, u0, fast_rcp(d0));
+    diag_plus_one(a[0][0][0], a[0][0][1], a[0][0][2], a[0][0][3]);
     bad |= b;
   }
 };
