@@ -3,8 +3,12 @@
 The reference shards the same way across MPI ranks: every rank solves the cell problems of the
 macro cells it owns (/root/reference/src/hommx/hmm.py:307-310, docs/usage/usage.md:64-71) and the
 results meet in PETSc's MatAssembly stash (hmm.py:325-330, :442).  Here the micro problems never
-communicate; the only exchange is ONE all-gather of the effective-tensor field (N_c x t x t doubles,
-<= a few MB: latency-bound), so that every rank can assemble the macro matrix.
+communicate; the only exchange is ONE all-gather of the effective-tensor field together with the
+per-cell info flags (N_c x (t*t + 1) doubles, <= a few MB: latency-bound), so that every rank can
+assemble the macro matrix and log failed cells exactly as a single rank would (hmm.py:320-323).
+
+Every rank samples, uploads and solves ONLY its own block of cells; on the RCCL backend the shard
+stays in device memory from the solve to the collective (one D2H copy of the gathered field).
 """
 
 from __future__ import annotations
@@ -22,11 +26,28 @@ def shard_range(n_cells: int, rank: int, world: int) -> tuple[int, int, int]:
     return b, e, per
 
 
-def all_gather_field(local, n_cells: int, group=None):
-    """All-gather the per-rank shard of the effective-tensor field.
+def default_device() -> int:
+    """Device ordinal a rank should use when the caller did not choose one: LOCAL_RANK under torchrun, else the
+    current torch device when a process group with more than one rank exists, else 0."""
+    import os
+    import sys
 
-    ``local`` is a torch tensor [per_rank, t, t] (padded shard) on this rank's device (RCCL) or on the
-    CPU (gloo); returns the full field [n_cells, t, t] on the same device on every rank.
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if "LOCAL_RANK" in os.environ:
+            return int(os.environ["LOCAL_RANK"])
+        import torch
+
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+    return 0
+
+
+def all_gather_field(local, n_cells: int, group=None):
+    """All-gather the per-rank shard of a field.
+
+    ``local`` is a torch tensor [per_rank, ...] (padded shard) on this rank's device (RCCL) or on the
+    CPU (gloo); returns the full field [n_cells, ...] on the same device on every rank.
     """
     import torch
     import torch.distributed as dist
@@ -38,48 +59,118 @@ def all_gather_field(local, n_cells: int, group=None):
     return full[:n_cells]
 
 
-def _gather_shards(plan, n_cells: int, solve_range, group=None, device=None):
-    """Run ``solve_range(b, e)`` on this rank's block of cells and all-gather the field over the group's backend."""
+def _unpad_index(n_cells: int, per: int, world: int) -> np.ndarray:
+    """Positions of the real cells in the concatenation of the padded shards."""
+    return np.concatenate([np.arange(r * per, r * per + max(0, min(n_cells, (r + 1) * per) - min(n_cells, r * per)))
+                           for r in range(world)])
+
+
+def run_sharded(t: int, n_cells: int, local_solve, group=None, device=None):
+    """Solve this rank's block with ``local_solve(b, e) -> (A[e-b, t, t], info[e-b])`` and all-gather both.
+
+    ``local_solve`` may return NumPy arrays or torch tensors (on the rank's GPU: the shard then never leaves the device before
+    the collective).  The tensors and the info flags travel in ONE packed buffer [per_rank, t*t + 1] (info as a double: small
+    integers are exact).  Returns NumPy ``(A_eff[n_cells, t, t], info[n_cells] int32)`` on every rank.
+    """
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     b, e, per = shard_range(n_cells, rank, world)
-    t = plan.t
-    local = np.zeros((per, t, t))
-    if e > b:
-        local[: e - b] = solve_range(b, e)
-    tl = torch.from_numpy(local)
-    if device is None and dist.get_backend(group) == "nccl":  # RCCL moves device memory only
-        device = torch.device("cuda", getattr(plan, "device", torch.cuda.current_device()))
-    if device is not None:
-        tl = tl.to(device)
-    full = all_gather_field(tl, world * per, group)
-    # padded shards sit at the tail of every rank's block; strip them
-    idx = np.concatenate([np.arange(r * per, r * per + max(0, min(n_cells, (r + 1) * per) - min(n_cells, r * per)))
-                          for r in range(world)])
-    return full.cpu().numpy()[idx]
+    nloc = e - b
+    A = info = None
+    if nloc > 0:
+        A, info = local_solve(b, e)
+    on_gpu = torch.is_tensor(A) and A.is_cuda
+    if device is None:
+        if on_gpu:
+            device = A.device
+        elif dist.get_backend(group) == "nccl":  # RCCL moves device memory only
+            device = torch.device("cuda", default_device())
+    buf = torch.zeros((per, t * t + 1), dtype=torch.float64, device=device if device is not None else "cpu")
+    if nloc > 0:
+        At = A if torch.is_tensor(A) else torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64))
+        it = info if torch.is_tensor(info) else torch.from_numpy(np.ascontiguousarray(info))
+        buf[:nloc, : t * t] = At.reshape(nloc, t * t).to(buf.device)
+        buf[:nloc, t * t] = it.to(buf.device, dtype=torch.float64)
+    full = all_gather_field(buf, world * per, group).cpu().numpy()[_unpad_index(n_cells, per, world)]
+    return full[:, : t * t].reshape(n_cells, t, t).copy(), np.rint(full[:, t * t]).astype(np.int32)
 
 
-def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, device=None):
-    """Solve this rank's block of macro cells and all-gather the field (host-array convenience path).
+def _has_device_entry(plan) -> bool:
+    return hasattr(plan, "solve_device") and hasattr(plan, "device")
 
-    With an initialised process group the exchange runs over the group's backend (``nccl`` = RCCL on
-    the GPUs, ``gloo`` in the CPU tests, where ``plan`` may be any object with ``.solve`` and ``.t``).
-    Without one it degenerates to ``plan.solve``.
-    """
+
+def solve_block(plan, coef: np.ndarray, M: np.ndarray | None):
+    """One rank's block through ``plan``: on a real plan under the RCCL backend the result stays on the device
+    (torch tensors, torch's current stream); otherwise ``plan.solve`` on host arrays."""
+    import torch
+    import torch.distributed as dist
+
+    if _has_device_entry(plan) and dist.is_initialized() and dist.get_backend() == "nccl":
+        dev = torch.device("cuda", plan.device)
+        nc = coef.shape[0]
+        c = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(dev)
+        m = None if M is None else torch.from_numpy(np.ascontiguousarray(M, dtype=np.float64)).to(dev)
+        out = torch.empty((nc, plan.t, plan.t), dtype=torch.float64, device=dev)
+        info = torch.zeros(nc, dtype=torch.int32, device=dev)
+        plan.solve_device(nc, c.data_ptr(), None if m is None else m.data_ptr(), out.data_ptr(), info.data_ptr(),
+                          torch.cuda.current_stream(dev).cuda_stream)
+        return out, info
+    res = plan.solve(coef, M, return_info=True) if _accepts_return_info(plan.solve) else (plan.solve(coef, M), None)
+    A, info = res
+    return A, (np.zeros(len(coef), np.int32) if info is None else info)
+
+
+def solve_block_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None):
+    import torch
+    import torch.distributed as dist
+
+    if hasattr(plan, "solve_two_phase_device") and hasattr(plan, "device") and dist.is_initialized() and dist.get_backend() == "nccl":
+        dev = torch.device("cuda", plan.device)
+        nc = values.shape[0]
+        mk = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8))).to(dev)
+        v = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(dev)
+        m = None if M is None else torch.from_numpy(np.ascontiguousarray(M, dtype=np.float64)).to(dev)
+        out = torch.empty((nc, plan.t, plan.t), dtype=torch.float64, device=dev)
+        info = torch.zeros(nc, dtype=torch.int32, device=dev)
+        plan.solve_two_phase_device(nc, mk.data_ptr(), v.data_ptr(), None if m is None else m.data_ptr(), out.data_ptr(),
+                                    info.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        return out, info
+    if _accepts_return_info(plan.solve_two_phase):
+        return plan.solve_two_phase(mask, values, M, return_info=True)
+    return plan.solve_two_phase(mask, values, M), np.zeros(len(values), np.int32)
+
+
+def _accepts_return_info(fn) -> bool:
+    import inspect
+
+    try:
+        return "return_info" in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, device=None, return_info: bool = False):
+    """Convenience form for callers that hold the whole batch: every rank solves its block of ``coef`` / ``M`` and the field
+    (and info) is all-gathered.  With no process group it degenerates to ``plan.solve``.  ``plan`` may be any object with
+    ``.solve`` and ``.t`` (the gloo tests use the CPU oracle)."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
-        return plan.solve(coef, M)
-    return _gather_shards(plan, coef.shape[0], lambda b, e: plan.solve(coef[b:e], None if M is None else M[b:e]), group, device)
+        return plan.solve(coef, M, return_info=True) if return_info else plan.solve(coef, M)
+    A, info = run_sharded(plan.t, coef.shape[0], lambda b, e: solve_block(plan, coef[b:e], None if M is None else M[b:e]),
+                          group, device)
+    return (A, info) if return_info else A
 
 
-def solve_sharded_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None, group=None, device=None):
-    """Same for two-phase media (``plan.solve_two_phase``): every rank holds the phase mask, the per-cell phase values shard."""
+def solve_sharded_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None, group=None, device=None,
+                            return_info: bool = False):
+    """Same for two-phase media: every rank holds the phase mask, the per-cell phase values shard."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
-        return plan.solve_two_phase(mask, values, M)
-    return _gather_shards(plan, values.shape[0],
-                          lambda b, e: plan.solve_two_phase(mask, values[b:e], None if M is None else M[b:e]), group, device)
+        return plan.solve_two_phase(mask, values, M, return_info=True) if return_info else plan.solve_two_phase(mask, values, M)
+    A, info = run_sharded(plan.t, values.shape[0],
+                          lambda b, e: solve_block_two_phase(plan, mask, values[b:e], None if M is None else M[b:e]), group, device)
+    return (A, info) if return_info else A

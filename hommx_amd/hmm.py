@@ -147,10 +147,17 @@ class BaseHMM(ABC):
         petsc_options_cell_problem: dict | None = None,
         petsc_options_prefix: str = "hommx_HMM",
         *,
-        quadrature_degree: int = 0,
+        quadrature_degree: int | None = None,
         rhs_quadrature_degree: int = 6,
-        device: int = 0,
+        device: int | None = None,
     ):
+        """``quadrature_degree``: degree of the micro quadrature rule that samples ``A(x, .)``.  The reference lets UFL estimate it
+        from the expression (hmm.py:190-198 + fem.form at :644-647): 0 for a ``conditional`` between constants, 3 for one
+        transcendental function of the fast variable -- ``sin(2 pi y0)``, ``1/(2 + cos(2 pi y0))``: the coefficients of its own
+        tests (test_integration_poisson.py:124-125, 149-150, 197).  A Python callable has no expression tree, so the default
+        ``None`` decides by looking at the samples: piecewise constant on every micro element -> centroid rule (degree 0),
+        anything else -> degree 3.  Pass an integer to choose the rule yourself (polynomial coefficients of another degree).
+        ``device``: HIP device ordinal; default LOCAL_RANK under an initialised torch.distributed group, else 0."""
         self._logger = logging.getLogger(__name__)
         self._msh = msh
         self._comm = msh.comm
@@ -171,8 +178,16 @@ class BaseHMM(ABC):
             raise ValueError("Micro and macro mesh should have the same dimensionality.")  # hmm.py:114-115
         self._n_micro = micro_cells_per_side(msh_micro)
         self._cell_mesh_area = float(msh_micro.cell_volumes().sum())  # hmm.py:101
-        self._quadrature_degree = quadrature_degree
+        if isinstance(A, TwoPhase) and quadrature_degree not in (None, 0, 1):
+            raise ValueError("a TwoPhase coefficient is piecewise constant in y (UFL: degree 0, centroid rule); "
+                             f"quadrature_degree={quadrature_degree} would be ignored by the device sampler")
+        self._quadrature_degree = quadrature_degree  # None: decided from the samples on first use (quadrature_degree_used)
+        self.quadrature_degree_used: int | None = 0 if isinstance(A, TwoPhase) else quadrature_degree
         self._rhs_degree = rhs_quadrature_degree
+        if device is None:
+            from .dist import default_device
+
+            device = default_device()
         self._device = device
 
         self._V_macro = self._setup_macro_function_space()
@@ -225,9 +240,22 @@ class BaseHMM(ABC):
             v = np.broadcast_to(v, (yq.shape[1],) + v.shape).copy()
         return v
 
+    def _auto_quadrature_degree(self, c_T: np.ndarray) -> int:
+        """Default policy (see __init__): sample A(c_T, .) at the degree-3 points of every micro element; if all points of
+        each element agree the coefficient is piecewise constant (UFL's degree 0 for a conditional), else degree 3."""
+        d = self._tdim
+        bary, _ = micro_quadrature(d, 3)
+        Xe = self._cell_mesh.cell_vertices()
+        yq = np.einsum("qa,eak->eqk", bary, Xe)
+        v = self._sample_one(c_T, yq.reshape(-1, d).T)
+        v = v.reshape((yq.shape[0], yq.shape[1]) + v.shape[1:])
+        return 0 if np.all(v == v[:, :1]) else 3
+
     def _element_means(self, cells: np.ndarray) -> tuple[np.ndarray, str]:
         d = self._tdim
-        bary, w = micro_quadrature(d, self._quadrature_degree)
+        if self.quadrature_degree_used is None:
+            self.quadrature_degree_used = self._auto_quadrature_degree(self._msh.cell_midpoints()[0])
+        bary, w = micro_quadrature(d, self.quadrature_degree_used)
         Xe = self._cell_mesh.cell_vertices()  # [n_el, d+1, d]
         yq = np.einsum("qa,eak->eqk", bary, Xe)
         n_el, nq = yq.shape[:2]
@@ -287,6 +315,11 @@ class BaseHMM(ABC):
             if means.ndim == 2:
                 return means, "poisson"
             if means.shape[-2:] == (d, d):
+                asym = np.abs(means - np.swapaxes(means, -1, -2)).max() if means.size else 0.0
+                if asym > 1e-12 * max(1.0, float(np.abs(means).max())):
+                    raise ValueError("matrix-valued A must be symmetric: the kernels form the Schur complement C0 - B^T K^+ B, which "
+                                     "equals the reference's energy functional (hmm.py:652-667) only for symmetric A "
+                                     f"(max |A - A^T| = {asym:.3e})")
                 pairs = _VOIGT[d]
                 return np.stack([0.5 * (means[..., i, j] + means[..., j, i]) for i, j in pairs], axis=-1), "poisson_matrix"
             raise ValueError(f"PoissonHMM coefficient must be scalar or {d}x{d}; got trailing shape {means.shape[2:]}")
@@ -313,47 +346,66 @@ class BaseHMM(ABC):
         return M
 
     # -- the hot path (replaces the loop hmm.py:298-332) ---------------------------------------------
+    @staticmethod
+    def _sharded() -> bool:
+        """Only shard when the caller already runs under an initialised torch.distributed group with more than one rank."""
+        import sys
+
+        dist = sys.modules.get("torch.distributed")
+        return dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _ensure_plan(self, kind: str) -> MicroCellPlan:
+        if self._plan is None or self._plan.kind != kind:
+            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
+        return self._plan
+
+    def _tensor_size(self) -> int:
+        d = self._tdim
+        return d if self._kind == "poisson" else d * (d + 1) // 2
+
     def _effective_tensors(self, cells: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """A_H / C_H and the per-cell info flags of ``cells``.  Under a process group every rank samples, uploads and solves
+        ONLY its block of the cells (the reference's MPI partition, hmm.py:307-310); one all-gather returns the whole field and
+        the real info vector to every rank (hommx_amd/dist.py)."""
         if isinstance(self._coeff, TwoPhase):
             res = self._effective_tensors_two_phase(cells)
             if res is not None:
                 return res
+        if self._sharded():
+            from .dist import run_sharded, solve_block
+
+            def local(b, e):
+                sub = cells[b:e]
+                coef, kind = self._element_means(sub)
+                return solve_block(self._ensure_plan(kind), coef, self._stratification(sub))
+
+            return run_sharded(self._tensor_size(), len(cells), local)
         coef, kind = self._element_means(cells)
         M = self._stratification(cells)
-        if self._plan is None or self._plan.kind != kind:
-            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
-        import sys
-
-        dist = sys.modules.get("torch.distributed")  # only shard when the caller already runs under torch.distributed
-        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from .dist import solve_sharded
-
-            AH = solve_sharded(self._plan, coef, M)
-            return AH, np.zeros(len(cells), dtype=np.int32)
-        return self._plan.solve(coef, M, return_info=True)
+        return self._ensure_plan(kind).solve(coef, M, return_info=True)
 
     def _effective_tensors_two_phase(self, cells: np.ndarray):
         """Device-side sampling of a ``TwoPhase`` coefficient: one mask + two values per macro cell."""
         kind = "poisson" if self._kind == "poisson" else "elasticity"
-        if self._plan is None or self._plan.kind != kind:
-            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
-        if not hasattr(self._plan, "solve_two_phase"):
+        plan = self._ensure_plan(kind)
+        if not hasattr(plan, "solve_two_phase"):
             return None
         d = self._tdim
         yb = self._cell_mesh.cell_midpoints()[:, :d].T  # element barycentres
         mask = np.asarray(self._coeff.indicator(yb), dtype=bool)
-        values = self._coeff.phase_values(self._msh.cell_midpoints()[cells])
-        if (values.ndim == 2) != (kind == "poisson"):
-            raise ValueError("TwoPhase values must be scalars for PoissonHMM and Lame(lam, mu) for LinearElasticityHMM")
-        M = self._stratification(cells)
-        import sys
 
-        dist = sys.modules.get("torch.distributed")  # only shard when the caller already runs under torch.distributed
-        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from .dist import solve_sharded_two_phase
+        def values_of(sub):
+            v = self._coeff.phase_values(self._msh.cell_midpoints()[sub])
+            if (v.ndim == 2) != (kind == "poisson"):
+                raise ValueError("TwoPhase values must be scalars for PoissonHMM and Lame(lam, mu) for LinearElasticityHMM")
+            return v
 
-            return solve_sharded_two_phase(self._plan, mask, values, M), np.zeros(len(cells), dtype=np.int32)
-        return self._plan.solve_two_phase(mask, values, M, return_info=True)
+        if self._sharded():
+            from .dist import run_sharded, solve_block_two_phase
+
+            return run_sharded(self._tensor_size(), len(cells),
+                               lambda b, e: solve_block_two_phase(plan, mask, values_of(cells[b:e]), self._stratification(cells[b:e])))
+        return plan.solve_two_phase(mask, values_of(cells), self._stratification(cells), return_info=True)
 
     def _local_stiffness_from_tensors(self, cells: np.ndarray, AH: np.ndarray) -> np.ndarray:
         """S_loc = vol(T)/vol(Y) * (macro gradients) A_H (macro gradients)^T  == hmm.py:361-369."""

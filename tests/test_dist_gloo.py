@@ -39,7 +39,8 @@ def _worker(rank, world, port, n_cells, q):
     rng = np.random.default_rng(3)
     coef = rng.uniform(0.1, 3.0, size=(n_cells, 2 * 6 * 6))
     M = np.eye(2)[None] + 0.2 * rng.standard_normal((n_cells, 2, 2))
-    full = solve_sharded(_OraclePlan(), coef, M)
+    full, info = solve_sharded(_OraclePlan(), coef, M, return_info=True)
+    assert info.shape == (n_cells,) and not info.any()
     mask = rng.uniform(size=coef.shape[1]) < 0.5
     values = rng.uniform(0.1, 3.0, size=(n_cells, 2))
     full2 = solve_sharded_two_phase(_OraclePlan(), mask, values, M)
@@ -72,3 +73,98 @@ def test_two_rank_shard_and_allgather():
     mask = rng.uniform(size=coef.shape[1]) < 0.5
     values = rng.uniform(0.1, 3.0, size=(n_cells, 2))
     assert np.array_equal(full2, _OraclePlan().solve_two_phase(mask, values, M))
+
+
+# ---- end to end: PoissonHMM.solve() on two ranks (hmm.py:298-332 + :434-491 with the reference's MPI partition :307-310) ----------
+class _CountingOraclePlan:
+    """Stand-in for MicroCellPlan (oracle answers): records which cells this rank was asked to solve and flags one poisoned cell
+    (non-positive coefficient) in info, as the kernels do (include/hommx_hip.h: info[c] > 0 = bad pivot)."""
+
+    kind = "poisson"
+    t = 2
+
+    def __init__(self):
+        self.batches = []
+
+    def solve(self, coef, M=None, return_info=False, return_correctors=False):
+        from oracle import hommx_oracle as O
+
+        self.batches.append(coef.shape[0])
+        n = int(round(np.sqrt(coef.shape[1] / 2)))
+        info = (coef.min(axis=1) <= 0).astype(np.int32) * 3
+        safe = np.where(coef > 0, coef, 1.0)
+        A = O.effective_tensor_batch("poisson", 2, n, safe, M)
+        A[info != 0] = np.nan
+        return (A, info) if return_info else A
+
+
+def _hmm_problem(poison_cell=None):
+    from hommx_amd import hmm, mesh
+
+    msh = mesh.create_unit_square(3, 3)  # 18 macro cells -> 9 per rank
+    c = msh.cell_midpoints()
+
+    def A(x, y):
+        base = 0.33 + 0.15 * (np.sin(2 * np.pi * x[0]) + np.sin(2 * np.pi * y[0]))
+        if poison_cell is not None:  # make exactly one macro cell's coefficient non-positive
+            base = np.where(np.isclose(x[0], c[poison_cell, 0]) & np.isclose(x[1], c[poison_cell, 1]), -1.0, base)
+        return base
+
+    return hmm.PoissonHMM(msh, A, lambda x: 1.0 + x[0], mesh.create_unit_square(6, 6), 0.01)
+
+
+def _hmm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import logging
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for tag, poison in (("clean", None), ("poisoned", 13)):
+        h = _hmm_problem(poison)
+        plan = _CountingOraclePlan()
+        h._plan = plan
+        errors = []
+        handler = logging.Handler()
+        handler.emit = lambda rec, errors=errors: errors.append(rec.getMessage())
+        logging.getLogger("hommx_amd.hmm").addHandler(handler)
+        u = h.solve()
+        logging.getLogger("hommx_amd.hmm").removeHandler(handler)
+        out[tag] = dict(u=u.x.array.copy(), info=h.cell_info.copy(), batches=list(plan.batches), errors=errors,
+                        AH=h.effective_tensors.copy(), qdeg=h.quadrature_degree_used)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_hmm_solve_end_to_end():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hmm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-rank answer in this process (no process group here)
+    h = _hmm_problem(None)
+    h._plan = _CountingOraclePlan()
+    u_ref = h.solve().x.array
+    assert h.quadrature_degree_used == 3  # smooth coefficient: the default policy picks UFL's estimate
+    for r in (0, 1):
+        clean = got[r]["clean"]
+        assert clean["qdeg"] == 3
+        assert clean["batches"] == [9]                      # every rank sampled and solved ONLY its 9 cells
+        assert np.array_equal(clean["AH"], h.effective_tensors)
+        assert np.array_equal(clean["u"], u_ref)             # macro solution identical to the single-rank one, on both ranks
+        assert not clean["info"].any() and not clean["errors"]
+        bad = got[r]["poisoned"]
+        assert bad["info"][13] == 3 and bad["info"].sum() == 3   # the poisoned cell's flag survives the all-gather on both ranks
+        assert any("cell 13" in m for m in bad["errors"])        # and is logged like the reference (hmm.py:320-323)

@@ -27,8 +27,14 @@ def test_sharded_solve_over_rccl_single_rank():
         rng = np.random.default_rng(1)
         p = MicroCellPlan(2, 16, "poisson")
         coef = rng.uniform(0.1, 3.0, size=(37, 512)); M = np.eye(2)[None] + 0.2 * rng.standard_normal((37, 2, 2))
-        full = solve_sharded(p, coef, M)                      # host arrays in, RCCL moves device memory
-        assert np.array_equal(full, p.solve(coef, M))
+        full, info = solve_sharded(p, coef, M, return_info=True)   # the shard stays on the device from the solve to the collective
+        assert np.array_equal(full, p.solve(coef, M)) and info.dtype == np.int32 and not info.any()
+        bad = coef.copy(); bad[5] = -1.0                           # a poisoned cell: its info flag travels with the field
+        _, info = solve_sharded(p, bad, M, return_info=True)
+        assert info[5] > 0 and (info != 0).sum() == 1
+        from hommx_amd.dist import solve_sharded_two_phase
+        mask = rng.uniform(size=512) < 0.4; vals = rng.uniform(0.1, 3.0, size=(37, 2))
+        assert np.array_equal(solve_sharded_two_phase(p, mask, vals, M), p.solve_two_phase(mask, vals, M))
         out = torch.from_numpy(full).cuda()
         g = all_gather_field(out, 37)                         # device tensor in, device tensor out (bench.py's use)
         assert g.is_cuda and torch.equal(g, out)
