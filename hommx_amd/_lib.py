@@ -26,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "hommx_solve_batch_correctors",
     "hommx_solve_batch_two_phase",
     "hommx_solve_batch_two_phase_device",
+    "hommx_solve_batch_separable",
+    "hommx_solve_batch_separable_device",
     "hommx_calibrate_fp64_mfma",
     "hommx_last_error",
 )
@@ -34,6 +36,8 @@ KIND_POISSON_SCALAR = 0
 KIND_POISSON_MATRIX = 1
 KIND_ELASTICITY_ISO = 2
 KIND_ELASTICITY_VOIGT = 3
+SAMPLER_AFFINE = 0
+SAMPLER_RECIPROCAL = 1
 
 
 class PlanDesc(C.Structure):
@@ -118,6 +122,10 @@ def load():
     lib.hommx_solve_batch_two_phase.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.hommx_solve_batch_two_phase_device.restype = C.c_int
     lib.hommx_solve_batch_two_phase_device.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.hommx_solve_batch_separable.restype = C.c_int
+    lib.hommx_solve_batch_separable.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.hommx_solve_batch_separable_device.restype = C.c_int
+    lib.hommx_solve_batch_separable_device.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.hommx_calibrate_fp64_mfma.restype = C.c_int
     lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
     lib.hommx_last_error.restype = C.c_char_p

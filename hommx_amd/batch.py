@@ -120,6 +120,47 @@ class MicroCellPlan:
             )
         return (out, info) if return_info else out
 
+    def solve_separable(self, family: str, table: np.ndarray, weights: np.ndarray | None, params: np.ndarray,
+                        M: np.ndarray | None = None, return_info: bool = False):
+        """Separable coefficient sampled on the device (include/hommx_hip.h): ``family`` "affine" (table[n_el] = element means of
+        g) or "reciprocal" (table[n_el, n_q] = g at the quadrature points, weights[n_q]); params[N_c, 2] = (a, b) per macro cell."""
+        fam = {"affine": _lib.SAMPLER_AFFINE, "reciprocal": _lib.SAMPLER_RECIPROCAL}[family]
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        nq = 1 if fam == _lib.SAMPLER_AFFINE else int(table.shape[1])
+        if table.size != self.n_el * nq:
+            raise ValueError(f"table has shape {table.shape}; expected ({self.n_el}" + (f", {nq})" if nq > 1 else ",)"))
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if fam == _lib.SAMPLER_RECIPROCAL and (w is None or w.shape != (nq,)):
+            raise ValueError(f"weights must have shape ({nq},)")
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        nc = params.shape[0]
+        if params.shape != (nc, 2):
+            raise ValueError(f"params has shape {params.shape}; expected ({nc}, 2)")
+        Mp = None
+        if M is not None:
+            M = np.ascontiguousarray(M, dtype=np.float64)
+            if M.shape != (nc, self.dim, self.dim):
+                raise ValueError(f"M has shape {M.shape}; expected ({nc}, {self.dim}, {self.dim})")
+            Mp = M.ctypes.data
+        out = np.empty((nc, self.t, self.t), dtype=np.float64)
+        info = np.zeros(nc, dtype=np.int32)
+        if nc:
+            _lib.check(
+                self._lib.hommx_solve_batch_separable(self._h, nc, fam, nq, table.ctypes.data, None if w is None else w.ctypes.data,
+                                                      params.ctypes.data, Mp, out.ctypes.data, info.ctypes.data),
+                "hommx_solve_batch_separable",
+            )
+        return (out, info) if return_info else out
+
+    def solve_separable_device(self, n_cells: int, family: str, n_q: int, table_ptr: int, weights_ptr: int | None, params_ptr: int,
+                               M_ptr: int | None, out_ptr: int, info_ptr: int | None, stream: int | None = None):
+        fam = {"affine": _lib.SAMPLER_AFFINE, "reciprocal": _lib.SAMPLER_RECIPROCAL}[family]
+        _lib.check(
+            self._lib.hommx_solve_batch_separable_device(self._h, int(n_cells), fam, int(n_q), table_ptr, weights_ptr or None, params_ptr,
+                                                         M_ptr or None, out_ptr, info_ptr or None, stream or None),
+            "hommx_solve_batch_separable_device",
+        )
+
     def solve_two_phase_device(self, n_cells: int, mask_ptr: int, values_ptr: int, M_ptr: int | None, out_ptr: int,
                                info_ptr: int | None, stream: int | None = None):
         _lib.check(

@@ -217,7 +217,10 @@ int hommx_solve_batch_two_phase_device(hommx_plan* p, int64_t n_cells, const uin
   HIP_TRY(hipSetDevice(p->desc.device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (p->family == FAM_FUSED2D) {
-    HIP_TRY(hommx::launch_poisson2d_fused(d_values, d_M, d_A_eff, d_info, p->desc.n_micro, n_cells, st, d_mask));
+    hommx::CoefSource src;
+    src.mode = hommx::COEF_TWO_PHASE;
+    src.table = d_mask;
+    HIP_TRY(hommx::launch_poisson2d_fused(d_values, d_M, d_A_eff, d_info, p->desc.n_micro, n_cells, st, src));
     return HOMMX_OK;
   }
   // blocked family: expand on the device, chunk by chunk of at most 1 GiB of element stream
@@ -281,6 +284,107 @@ int hommx_solve_batch_two_phase(hommx_plan* p, int64_t n_cells, const uint8_t* m
     HIP_TRY_C(hipMemcpy(d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
   }
   int rc = hommx_solve_batch_two_phase_device(p, n_cells, d_mask, d_values, d_M, d_out, d_info, nullptr);
+  if (rc != HOMMX_OK) {
+    cleanup();
+    return rc;
+  }
+  HIP_TRY_C(hipDeviceSynchronize());
+  HIP_TRY_C(hipMemcpy(A_eff, d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
+  if (info) HIP_TRY_C(hipMemcpy(info, d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
+#undef HIP_TRY_C
+  cleanup();
+  return HOMMX_OK;
+}
+
+int hommx_solve_batch_separable_device(hommx_plan* p, int64_t n_cells, int32_t family, int32_t n_q, const double* d_table,
+                                       const double* d_weights, const double* d_params, const double* d_M, double* d_A_eff,
+                                       int32_t* d_info, void* stream) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (p->desc.kind != HOMMX_KIND_POISSON_SCALAR) return fail(HOMMX_EINVAL, "separable samplers are defined for the scalar Poisson kind");
+  if (family != HOMMX_SAMPLER_AFFINE && family != HOMMX_SAMPLER_RECIPROCAL) return fail(HOMMX_EINVAL, "unknown sampler family %d", family);
+  if (!d_table || !d_params || !d_A_eff) return fail(HOMMX_EINVAL, "null table / params / A_eff");
+  if (family == HOMMX_SAMPLER_RECIPROCAL && (n_q < 1 || !d_weights)) return fail(HOMMX_EINVAL, "reciprocal sampler needs n_q >= 1 and weights");
+  if (n_cells > 0x7fffffffll) return fail(HOMMX_EINVAL, "n_cells too large for one launch");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hommx::CoefSource src;
+  src.mode = family == HOMMX_SAMPLER_AFFINE ? hommx::COEF_AFFINE : hommx::COEF_RECIPROCAL;
+  src.nq = family == HOMMX_SAMPLER_AFFINE ? 1 : n_q;
+  src.table = d_table;
+  src.weights = d_weights;
+  if (p->family == FAM_FUSED2D) {
+    HIP_TRY(hommx::launch_poisson2d_fused(d_params, d_M, d_A_eff, d_info, p->desc.n_micro, n_cells, st, src));
+    return HOMMX_OK;
+  }
+  // blocked family: expand on the device, chunk by chunk of at most 1 GiB of element stream
+  const int64_t per = p->n_el;
+  int64_t chunk = (int64_t)((1ll << 27) / (per > 0 ? per : 1));
+  if (chunk < 1) chunk = 1;
+  if (chunk > n_cells) chunk = n_cells;
+  if (chunk > p->cap_expand) {
+    if (p->d_expand) hipFree(p->d_expand);
+    p->d_expand = nullptr;
+    p->cap_expand = 0;
+    HIP_TRY(hipMalloc(&p->d_expand, sizeof(double) * chunk * per));
+    p->cap_expand = chunk;
+  }
+  const int d = p->desc.dim, t = p->t;
+  for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
+    const int64_t nc = (n_cells - c0 < chunk) ? n_cells - c0 : chunk;
+    HIP_TRY(hommx::launch_expand_separable(src, d_params + 2 * c0, p->d_expand, p->n_el, nc, st));
+    int rc = hommx::blocked_solve(p->ws, nc, p->d_expand, d_M ? d_M + c0 * d * d : nullptr, d_A_eff + c0 * t * t,
+                                  d_info ? d_info + c0 : nullptr, st);
+    if (rc != 0) return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+  }
+  return HOMMX_OK;
+}
+
+int hommx_solve_batch_separable(hommx_plan* p, int64_t n_cells, int32_t family, int32_t n_q, const double* table,
+                                const double* weights, const double* params, const double* M, double* A_eff, int32_t* info) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (n_cells == 0) return HOMMX_OK;
+  if (!table || !params || !A_eff) return fail(HOMMX_EINVAL, "null table / params / A_eff");
+  if (family == HOMMX_SAMPLER_RECIPROCAL && (n_q < 1 || !weights)) return fail(HOMMX_EINVAL, "reciprocal sampler needs n_q >= 1 and weights");
+  HIP_TRY(hipSetDevice(p->desc.device));
+  const int d = p->desc.dim, t = p->t;
+  const int64_t ntab = p->n_el * (family == HOMMX_SAMPLER_AFFINE ? 1 : n_q);
+  double *d_table = nullptr, *d_w = nullptr, *d_params = nullptr, *d_M = nullptr, *d_out = nullptr;
+  int32_t* d_info = nullptr;
+  auto cleanup = [&]() {
+    if (d_table) hipFree(d_table);
+    if (d_w) hipFree(d_w);
+    if (d_params) hipFree(d_params);
+    if (d_M) hipFree(d_M);
+    if (d_out) hipFree(d_out);
+    if (d_info) hipFree(d_info);
+  };
+#define HIP_TRY_C(expr)                                                                             \
+  do {                                                                                              \
+    hipError_t e__ = (expr);                                                                        \
+    if (e__ != hipSuccess) {                                                                        \
+      cleanup();                                                                                    \
+      return fail(e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP, "%s failed: %s", #expr,   \
+                  hipGetErrorString(e__));                                                          \
+    }                                                                                               \
+  } while (0)
+  HIP_TRY_C(hipMalloc(&d_table, sizeof(double) * ntab));
+  HIP_TRY_C(hipMalloc(&d_params, sizeof(double) * n_cells * 2));
+  HIP_TRY_C(hipMalloc(&d_out, sizeof(double) * n_cells * t * t));
+  HIP_TRY_C(hipMalloc(&d_info, sizeof(int32_t) * n_cells));
+  HIP_TRY_C(hipMemcpy(d_table, table, sizeof(double) * ntab, hipMemcpyHostToDevice));
+  HIP_TRY_C(hipMemcpy(d_params, params, sizeof(double) * n_cells * 2, hipMemcpyHostToDevice));
+  if (weights && n_q > 0) {
+    HIP_TRY_C(hipMalloc(&d_w, sizeof(double) * n_q));
+    HIP_TRY_C(hipMemcpy(d_w, weights, sizeof(double) * n_q, hipMemcpyHostToDevice));
+  }
+  if (M) {
+    HIP_TRY_C(hipMalloc(&d_M, sizeof(double) * n_cells * d * d));
+    HIP_TRY_C(hipMemcpy(d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
+  }
+  int rc = hommx_solve_batch_separable_device(p, n_cells, family, n_q, d_table, d_w, d_params, d_M, d_out, d_info, nullptr);
   if (rc != HOMMX_OK) {
     cleanup();
     return rc;

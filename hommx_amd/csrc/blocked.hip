@@ -796,6 +796,33 @@ hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_
   return hipGetLastError();
 }
 
+// separable coefficients (kernels.h): same arithmetic, operation by operation, as the fused kernel's sampler
+__global__ void k_expand_separable(CoefSource src, const double* __restrict__ params, double* __restrict__ coef, long long n_el,
+                                   long long ncells) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * n_el) return;
+  const long long cell = idx / n_el, el = idx % n_el;
+  const double a = params[2 * cell], b = params[2 * cell + 1];
+  const double* table = static_cast<const double*>(src.table);
+  if (src.mode == COEF_AFFINE) {
+    coef[idx] = add_rn(a, mul_rn(b, table[el]));
+  } else {
+    double acc = 0.0;
+    for (int q = 0; q < src.nq; ++q)
+      acc = add_rn(acc, mul_rn(src.weights[q], div_rn(1.0, add_rn(a, mul_rn(b, table[el * src.nq + q])))));
+    coef[idx] = acc;
+  }
+}
+
+hipError_t launch_expand_separable(CoefSource src, const double* d_params, double* d_coef, long long n_el, long long ncells,
+                                   hipStream_t stream) {
+  const long long work = ncells * n_el;
+  if (work <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_expand_separable, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, src, d_params, d_coef, n_el,
+                     ncells);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------

@@ -76,7 +76,7 @@ struct alignas(16) Lds {
 template <int NB>
 __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fused(
     const double* __restrict__ coef, const double* __restrict__ Mmat, double* __restrict__ out,
-    int32_t* __restrict__ info, int n, long long ncells, const unsigned char* __restrict__ mask
+    int32_t* __restrict__ info, int n, long long ncells, const CoefSource src
 #ifdef HOMMX_FUSED_DEBUG
     , double* __restrict__ dbg
 #endif
@@ -128,24 +128,41 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
   const double ga = uniform_f64(0.5 * (m00 * m01 + m10 * m11));
   const double ab = uniform_f64(al - 2.0 * ga + be);
 
-  // Coefficient source: the element stream coef[cell][2 n^2], or -- two-phase media -- a phase mask shared by all
-  // cells (mask[2 n^2], one byte per element) and the two phase values of this cell, coef[cell][2] = (phase 0, phase 1).
-  const double* cc = mask ? coef + cell * 2 : coef + cell * (2ll * n * n);
-  double ph0 = 0.0, ph1 = 0.0;
-  if (mask) {
+  // Coefficient source (kernels.h): the element stream coef[cell][2 n^2], or a device sampler fed by two numbers per cell
+  const int mode = src.mode;
+  const unsigned char* mask = static_cast<const unsigned char*>(src.table);
+  const double* table = static_cast<const double*>(src.table);
+  const double* cc = mode == COEF_STREAM ? coef + cell * (2ll * n * n) : coef + cell * 2;
+  double ph0 = 0.0, ph1 = 0.0;  // phase values / (a, b)
+  if (mode != COEF_STREAM) {
     ph0 = cc[0];
     ph1 = cc[1];
   }
+  const int nq = src.nq;
+  auto sample = [&](long long el) {  // RECIPROCAL: sum_q w_q / (a + b g_q), every operation rounded separately, q ascending
+    double acc = 0.0;
+    for (int q = 0; q < nq; ++q)
+      acc = add_rn(acc, mul_rn(src.weights[q], div_rn(1.0, add_rn(ph0, mul_rn(ph1, table[el * nq + q])))));
+    return acc;
+  };
   auto load_row = [&](int jc) {
     CoefRow r;
     r.a0 = 0.0; r.a1 = 0.0;
     if (valid) {
-      if (mask) {
-        const uchar2 mk = *reinterpret_cast<const uchar2*>(mask + 2 * (jc * n + cn));
+      const long long el = 2 * (jc * n + cn);
+      if (mode == COEF_TWO_PHASE) {
+        const uchar2 mk = *reinterpret_cast<const uchar2*>(mask + el);
         r.a0 = mk.x ? ph1 : ph0;
         r.a1 = mk.y ? ph1 : ph0;
+      } else if (mode == COEF_AFFINE) {
+        const double2 g2 = *reinterpret_cast<const double2*>(table + el);
+        r.a0 = add_rn(ph0, mul_rn(ph1, g2.x));
+        r.a1 = add_rn(ph0, mul_rn(ph1, g2.y));
+      } else if (mode == COEF_RECIPROCAL) {
+        r.a0 = sample(el);
+        r.a1 = sample(el + 1);
       } else {
-        const double2 v = *reinterpret_cast<const double2*>(cc + 2 * (jc * n + cn));
+        const double2 v = *reinterpret_cast<const double2*>(cc + el);
         r.a0 = v.x; r.a1 = v.y;
       }
     }
@@ -636,20 +653,20 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 
 // ---- launch ---------------------------------------------------------------------------------------
 hipError_t launch_poisson2d_fused(const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
-                                  int n, long long ncells, hipStream_t stream, const unsigned char* d_mask) {
+                                  int n, long long ncells, hipStream_t stream, CoefSource src) {
   if (ncells <= 0) return hipSuccess;
   dim3 grid((unsigned)ncells), block(64);
 #ifdef HOMMX_FUSED_DEBUG
   extern double* g_fused_dbg;
   if (n <= 16)
-    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, d_mask, g_fused_dbg);
+    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src, g_fused_dbg);
   else
-    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, d_mask, g_fused_dbg);
+    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src, g_fused_dbg);
 #else
   if (n <= 16)
-    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, d_mask);
+    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src);
   else
-    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, d_mask);
+    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src);
 #endif
   return hipGetLastError();
 }

@@ -5,11 +5,42 @@
 
 namespace hommx {
 
+// Where the per-element coefficient of a scalar Poisson cell comes from (device samplers).
+//   STREAM      coef[cell][n_el]: element means sampled by the caller
+//   TWO_PHASE   mask[n_el] (uint8) selects coef[cell][0 / 1]
+//   AFFINE      A_K = a + b * table[K]                      coef[cell] = (a, b); table[n_el] = element means of g(y)
+//   RECIPROCAL  A_K = sum_q w[q] / (a + b * table[K][q])    coef[cell] = (a, b); table[n_el][nq] = g at the quadrature points
+// Every operation of AFFINE / RECIPROCAL is a separately rounded IEEE operation in a fixed order, so a host that evaluates the
+// same formula (hommx_amd.hmm.Separable.host_stream) gets the same bits.
+// separately rounded IEEE operations: hipcc contracts a * b + c into an fma by default (and __dmul_rn / __dadd_rn are plain
+// operators in the HIP headers), which a host evaluating the same formula with NumPy does not do
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ double div_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a / b;
+}
+enum CoefMode { COEF_STREAM = 0, COEF_TWO_PHASE = 1, COEF_AFFINE = 2, COEF_RECIPROCAL = 3 };
+struct CoefSource {
+  int mode = COEF_STREAM;
+  int nq = 0;
+  const void* table = nullptr;    // mask (uint8) or table (double)
+  const double* weights = nullptr;
+};
+
 // fused2d.hip: 2D scalar Poisson (optionally stratified), 3 <= n <= 32, one wave per macro cell.
-// d_mask == nullptr: d_coef is the element stream [ncells][2 n^2]; otherwise d_coef is [ncells][2] (phase values) and
-// d_mask[2 n^2] selects the phase of every element (two-phase media sampled in the kernel).
 hipError_t launch_poisson2d_fused(const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
-                                  int n, long long ncells, hipStream_t stream, const unsigned char* d_mask = nullptr);
+                                  int n, long long ncells, hipStream_t stream, CoefSource src = CoefSource());
+
+// blocked.hip: coef[cell][el] of a separable coefficient (AFFINE / RECIPROCAL) expanded into the element stream
+hipError_t launch_expand_separable(CoefSource src, const double* d_params, double* d_coef, long long n_el, long long ncells,
+                                   hipStream_t stream);
 
 // blocked.hip: coef[cell][el][comp] = mask[el] ? values[cell][1][comp] : values[cell][0][comp]
 hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_values, double* d_coef, long long n_el,

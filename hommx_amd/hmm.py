@@ -123,6 +123,54 @@ class TwoPhase:
         return np.where(m, vin, vout)
 
 
+class Separable:
+    """Separable scalar coefficient  A(x, y) = a(x) + b(x) g(y)  (``family="affine"``)  or  1 / (a(x) + b(x) g(y))
+    (``family="reciprocal"``) -- the shape of the smooth coefficients in the reference's own tests
+    (test_integration_poisson.py:124-125  1/(2 + cos 2 pi y0);  :149-150, 197  0.33 + 0.15 (sin 2 pi x0 + sin 2 pi y0);
+    :268  1.1 + x0 + sin 2 pi y0).  Passing one as ``A`` of a Poisson solver class lets it sample on the DEVICE
+    (``hommx_solve_batch_separable``): g is tabulated once on the micro mesh at the points of the degree-3 rule UFL would
+    pick, and two numbers per macro cell cross the boundary instead of n_el samples.
+
+    ``a(x)`` / ``b(x)``: x[3, N_c] -> scalar or [N_c];  ``g(y)``: y[dim, npts] -> [npts].  The object is also a plain callable
+    ``A(x, y)``.  ``host_stream`` is the documented host equivalent of the device sampler: the same IEEE operations in the same
+    order, hence the same bits (tests/test_gpu_separable.py)."""
+
+    def __init__(self, family: str, a, b, g):
+        if family not in ("affine", "reciprocal"):
+            raise ValueError("family must be 'affine' or 'reciprocal'")
+        self.family, self.a, self.b, self.g = family, a, b, g
+
+    def params(self, c: np.ndarray) -> np.ndarray:
+        """[N_c, 2] = (a, b) at the macro cell midpoints c[N_c, 3]."""
+        n = c.shape[0]
+        return np.stack([np.broadcast_to(np.asarray(self.a(c.T), float), (n,)), np.broadcast_to(np.asarray(self.b(c.T), float), (n,))], axis=1)
+
+    def table(self, yq: np.ndarray, w: np.ndarray) -> np.ndarray:
+        """yq[n_el, n_q, dim] -> what the C ABI takes: affine: element means of g [n_el]; reciprocal: g at the points [n_el, n_q]."""
+        n_el, nq, d = yq.shape
+        gq = np.asarray(self.g(yq.reshape(-1, d).T), float).reshape(n_el, nq)
+        if self.family == "affine":
+            acc = np.zeros(n_el)
+            for q in range(nq):
+                acc = acc + w[q] * gq[:, q]
+            return acc
+        return gq
+
+    def host_stream(self, params: np.ndarray, table: np.ndarray, w: np.ndarray) -> np.ndarray:
+        """Element means coef[N_c, n_el] exactly as the device sampler forms them."""
+        a, b = params[:, 0:1], params[:, 1:2]
+        if self.family == "affine":
+            return a + b * table[None, :]
+        acc = np.zeros((params.shape[0], table.shape[0]))
+        for q in range(table.shape[1]):
+            acc = acc + w[q] * (1.0 / (a + b * table[None, :, q]))
+        return acc
+
+    def __call__(self, x, y):
+        v = self.a(x) + self.b(x) * self.g(y)
+        return v if self.family == "affine" else 1.0 / v
+
+
 def isotropic_hooke(lam, mu, dim: int) -> np.ndarray:
     lam, mu = np.asarray(lam, float), np.asarray(mu, float)
     I = np.eye(dim)
@@ -241,15 +289,20 @@ class BaseHMM(ABC):
         return v
 
     def _auto_quadrature_degree(self, c_T: np.ndarray) -> int:
-        """Default policy (see __init__): sample A(c_T, .) at the degree-3 points of every micro element; if all points of
-        each element agree the coefficient is piecewise constant (UFL's degree 0 for a conditional), else degree 3."""
+        """Default policy (see __init__): sample A(c_T, .) at the degree-3 points of every micro element.  A ``conditional``
+        between constants (UFL: degree 0, centroid rule) shows up as a coefficient that is constant on every element or -- when
+        its interface cuts through elements, like the wrapped disc of inclusion.py:107-118 -- takes only a handful of distinct
+        values over the whole cell; anything else is treated as smooth: degree 3."""
         d = self._tdim
         bary, _ = micro_quadrature(d, 3)
         Xe = self._cell_mesh.cell_vertices()
         yq = np.einsum("qa,eak->eqk", bary, Xe)
         v = self._sample_one(c_T, yq.reshape(-1, d).T)
         v = v.reshape((yq.shape[0], yq.shape[1]) + v.shape[1:])
-        return 0 if np.all(v == v[:, :1]) else 3
+        if np.all(v == v[:, :1]):
+            return 0
+        flat = v.reshape(v.shape[0] * v.shape[1], -1)
+        return 0 if all(np.unique(flat[:, k]).size <= 8 for k in range(flat.shape[1])) else 3
 
     def _element_means(self, cells: np.ndarray) -> tuple[np.ndarray, str]:
         d = self._tdim
@@ -371,6 +424,10 @@ class BaseHMM(ABC):
             res = self._effective_tensors_two_phase(cells)
             if res is not None:
                 return res
+        if isinstance(self._coeff, Separable) and self._kind == "poisson":
+            res = self._effective_tensors_separable(cells)
+            if res is not None:
+                return res
         if self._sharded():
             from .dist import run_sharded, solve_block
 
@@ -383,6 +440,29 @@ class BaseHMM(ABC):
         coef, kind = self._element_means(cells)
         M = self._stratification(cells)
         return self._ensure_plan(kind).solve(coef, M, return_info=True)
+
+    def _effective_tensors_separable(self, cells: np.ndarray):
+        """Device-side sampling of a ``Separable`` coefficient: one table of g on the micro mesh + (a, b) per macro cell."""
+        plan = self._ensure_plan("poisson")
+        if not hasattr(plan, "solve_separable"):
+            return None
+        d = self._tdim
+        if self.quadrature_degree_used is None:
+            self.quadrature_degree_used = self._auto_quadrature_degree(self._msh.cell_midpoints()[0])
+        bary, w = micro_quadrature(d, self.quadrature_degree_used)
+        yq = np.einsum("qa,eak->eqk", bary, self._cell_mesh.cell_vertices())
+        co = self._coeff
+        table = co.table(yq, w)
+
+        def local(sub):
+            return plan.solve_separable(co.family, table, w, co.params(self._msh.cell_midpoints()[sub]), self._stratification(sub),
+                                        return_info=True)
+
+        if self._sharded():
+            from .dist import run_sharded
+
+            return run_sharded(self._tensor_size(), len(cells), lambda b, e: local(cells[b:e]))
+        return local(cells)
 
     def _effective_tensors_two_phase(self, cells: np.ndarray):
         """Device-side sampling of a ``TwoPhase`` coefficient: one mask + two values per macro cell."""

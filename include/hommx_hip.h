@@ -113,6 +113,31 @@ int hommx_solve_batch_two_phase(hommx_plan* plan, int64_t n_cells, const uint8_t
 int hommx_solve_batch_two_phase_device(hommx_plan* plan, int64_t n_cells, const uint8_t* d_mask, const double* d_values,
                                        const double* d_M, double* d_A_eff, int32_t* d_info, void* stream);
 
+/*
+ * Separable coefficients sampled on the device.  The smooth coefficients of the reference's own tests are a
+ * slow amplitude times a fixed function of the fast variable:  A(x, y) = a(x) + b(x) g(y)  (test_integration_poisson.py:149-150,
+ * 197: 0.33 + 0.15 (sin 2 pi x0 + sin 2 pi y0); :268: 1.1 + x0 + sin 2 pi y0)  or its reciprocal  1 / (a(x) + b(x) g(y))
+ * (:124-125: 1 / (2 + cos 2 pi y0)).  g is tabulated ONCE on the micro mesh at the points of the quadrature rule UFL would pick
+ * (degree 3: 6 points per triangle); the kernels form the element means from (a, b) of each macro cell, so 16 bytes per cell
+ * cross the boundary instead of n_el samples.  Scalar Poisson kind only.
+ *
+ *   family   HOMMX_SAMPLER_AFFINE      A_K = a + b * table[K]                      table[n_el] = sum_q w_q g(y_{K,q})
+ *            HOMMX_SAMPLER_RECIPROCAL  A_K = sum_q weights[q] / (a + b * table[K][q])   table[n_el][n_q] = g(y_{K,q})
+ *   params   [n_cells][2] = (a, b) at the macro cell midpoint c_T
+ *
+ * Every operation is a separately rounded IEEE-754 operation in the written order (q ascending), so a host evaluating the same
+ * formula reproduces the element stream bit for bit (hommx_amd.hmm.Separable.host_stream; tests/test_gpu_separable.py).
+ */
+#define HOMMX_SAMPLER_AFFINE 0
+#define HOMMX_SAMPLER_RECIPROCAL 1
+int hommx_solve_batch_separable(hommx_plan* plan, int64_t n_cells, int32_t family, int32_t n_q, const double* table,
+                                const double* weights, const double* params, const double* M, double* A_eff, int32_t* info);
+
+/* Same with DEVICE pointers, asynchronous on `stream`. */
+int hommx_solve_batch_separable_device(hommx_plan* plan, int64_t n_cells, int32_t family, int32_t n_q, const double* d_table,
+                                       const double* d_weights, const double* d_params, const double* d_M, double* d_A_eff,
+                                       int32_t* d_info, void* stream);
+
 /* Same as hommx_solve_batch, additionally returning the correctors (host pointers):
  *   correctors [n_cells][t][n^d * bs]  chi_m of the canonical load case m (unit gradient e_m / unit strain E^m) at the
  *                                      periodic unknowns, dof = node * bs + component, node = i + n j [+ n^2 k];
