@@ -229,7 +229,8 @@ __global__ __launch_bounds__(128) void k_assemble(Geo G, const double* __restric
   }
 }
 
-// C0[cell][t][t] = sum_e vol Cv_e ; one block per cell
+// C0[cell][t][t] = sum_e vol Cv_e ; one block per cell.  Fixed summation order (thread-strided partial sums, wave butterfly,
+// four wave totals added in order): bitwise reproducible.
 __global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ coef, double* __restrict__ C0) {
   const long long cell = blockIdx.x;
   const int t = G.t, tt = t * t;
@@ -241,20 +242,19 @@ __global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ co
     element_matrix(G, ccell + (long long)e * G.ncomp, Cv);
     for (int i = 0; i < tt; ++i) acc[i] += Cv[i];
   }
-  __shared__ double red[256];
+  __shared__ double red[4][36];
   double vol = 1.0;
   for (int k = 0; k < G.dim; ++k) vol /= G.n;
   vol /= (G.dim == 2 ? 2.0 : 6.0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = 0; i < tt; ++i) {
-    red[threadIdx.x] = acc[i];
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) C0[cell * tt + i] = red[0] * vol;
-    __syncthreads();
+    double v = acc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
   }
+  __syncthreads();
+  if (threadIdx.x < tt) C0[cell * tt + threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * vol;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -823,6 +823,10 @@ hipError_t launch_expand_separable(CoefSource src, const double* d_params, doubl
   return hipGetLastError();
 }
 
+}  // namespace hommx
+#include "small_fused.h"
+namespace hommx {
+
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------
@@ -833,6 +837,7 @@ struct BlockedWorkspace {
   int gemm128_min = 256;       // HOMMX_GEMM128_MIN
   bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
   bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
+  bool small_fused = true;     // HOMMX_NO_SMALL_FUSED switches the LDS-resident kernel for b <= 64 off (A/B runs)
   long long chunk = 0;
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
   double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
@@ -908,6 +913,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   if (const char* e = getenv("HOMMX_GEMM128_MIN")) ws->gemm128_min = atoi(e);
   ws->sparse_v1 = getenv("HOMMX_SPARSE_V1") != nullptr;
   ws->leaf32 = getenv("HOMMX_LEAF32") != nullptr;
+  ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
   *out = ws;
   return 0;
 }
@@ -1286,6 +1292,28 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
 #undef HOMMX_ASM
     }
     hipLaunchKernelGGL(k_c0, dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0);
+    if (G.b <= 64 && !d_corr && ws->small_fused) {
+      // small plane blocks: the whole elimination in ONE launch, matrices in LDS (small_fused.h)
+      double* o = d_out + c0 * G.t * G.t;
+      int32_t* inf = d_info ? d_info + c0 : nullptr;
+      const int nipc = G.ncode / 3;
+      const int bp = G.b <= 32 ? 32 : G.b <= 48 ? 48 : 64;
+#define HOMMX_SF(BP_, BS_, NI_) hipLaunchKernelGGL((k_small_fused<BP_, BS_, NI_>), dim3((unsigned)nc), dim3((BP_ / 2) * (BP_ / 2)), 0, st, G, ws->Kst, ws->Brhs, ws->C0, o, inf, nc)
+#define HOMMX_SFK(BP_)                                                     \
+  do {                                                                     \
+    if (G.bs == 1 && nipc == 3) HOMMX_SF(BP_, 1, 3);                       \
+    else if (G.bs == 2) HOMMX_SF(BP_, 2, 3);                               \
+    else if (G.bs == 1) HOMMX_SF(BP_, 1, 9);                               \
+    else HOMMX_SF(BP_, 3, 9);                                              \
+  } while (0)
+      if (bp == 32) HOMMX_SFK(32);
+      else if (bp == 48) HOMMX_SFK(48);
+      else HOMMX_SFK(64);
+#undef HOMMX_SFK
+#undef HOMMX_SF
+      BTRY(hipGetLastError());
+      continue;
+    }
     // ---- K2 init
     BTRY(hipMemsetAsync(ws->S, 0, 8ll * nc * mat, st));
     BTRY(hipMemsetAsync(ws->W, 0, 8ll * nc * mat, st));

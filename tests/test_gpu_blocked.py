@@ -297,3 +297,44 @@ def test_large_tile_gemm_on_partial_tiles(tmp_path):
         coef, M = _g128_inputs(p, dim, 5)
         B = np.load(tmp_path / f"{kind}_{dim}_{n}.npy")
         assert np.abs(p.solve(coef, M) - B).max() <= 1e-12 * np.abs(B).max()
+
+
+def test_small_fused_route_equals_hbm_route(tmp_path):
+    """Plane blocks b <= 64 run in ONE LDS-resident launch (csrc/small_fused.h: BP = 32 / 48 / 64); HOMMX_NO_SMALL_FUSED (read when
+    the plan is created, hence the child process) sends the same inputs through the HBM-resident kernels of the blocked family.
+    Sizes of the reference's own tests: 2D elasticity 10 x 10 (test_integration_linear_elasticity.py:62-171), 3D Poisson 6^3
+    (test_integration_poisson.py:243-294); plus b = 64 (3D Poisson 8^3), b = 48 (3D elasticity 4^3) and matrix-valued 2D Poisson."""
+    import subprocess, textwrap
+
+    cases = [("elasticity", 2, 10), ("poisson", 3, 6), ("poisson", 3, 8), ("elasticity", 3, 4), ("poisson_matrix", 2, 16),
+             ("elasticity_voigt", 2, 7)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys; sys.path.insert(0, {root!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        for kind, dim, n in {cases!r}:
+            p = MicroCellPlan(dim, n, kind, flags=1)
+            rng = np.random.default_rng(11)
+            shape = (9, p.n_el) + ((p.n_comp,) if p.n_comp > 1 else ())
+            coef = rng.uniform(0.4, 2.5, size=shape)
+            if kind == "poisson_matrix":
+                coef[..., -1] = 0.2 * rng.uniform(-1, 1, size=shape[:2])
+            if kind == "elasticity_voigt":  # SPD 3 x 3: diagonally dominant upper triangle (00, 01, 02, 11, 12, 22)
+                coef[..., [1, 2, 4]] *= 0.1
+            M = np.eye(dim)[None] + 0.2 * rng.standard_normal((9, dim, dim))
+            A, info = p.solve(coef, M, return_info=True)
+            assert not info.any(), (kind, dim, n)
+            np.save(sys.argv[1] + f"/{{kind}}_{{dim}}_{{n}}.npy", A)
+        print("ok")
+    """)
+    outs = {}
+    for tag, env_extra in (("small", {}), ("hbm", {"HOMMX_NO_SMALL_FUSED": "1"})):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", code, str(d)], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+        outs[tag] = {c: np.load(d / f"{c[0]}_{c[1]}_{c[2]}.npy") for c in cases}
+    for c in cases:
+        assert relerr(outs["small"][c], outs["hbm"][c]) < 1e-10, c

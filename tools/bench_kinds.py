@@ -4,10 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hommx_amd import MicroCellPlan
 
+only_small = "--small" in sys.argv
+
 dev = torch.device("cuda:0")
-cases = [(2, 32, "poisson", 1, 4096), (2, 32, "poisson_matrix", 0, 4096), (2, 32, "elasticity", 0, 4096), (2, 16, "elasticity", 0, 4096),
+cases = [(2, 10, "elasticity", 0, 8192), (3, 6, "poisson", 0, 8192), (2, 16, "poisson_matrix", 0, 8192), (3, 8, "poisson", 0, 4096),
+         (2, 32, "poisson", 1, 4096), (2, 32, "poisson_matrix", 0, 4096), (2, 32, "elasticity", 0, 4096), (2, 16, "elasticity", 0, 4096),
          (2, 64, "poisson", 0, 2048), (3, 8, "poisson", 0, 2048), (3, 16, "poisson", 0, 1024), (3, 8, "elasticity", 0, 1024),
          (3, 12, "elasticity", 0, 1024), (3, 16, "elasticity", 0, 1024)]
+if only_small:
+    cases = cases[:4]
 for dim, n, kind, flags, nc in cases:
     p = MicroCellPlan(dim, n, kind, flags=flags)
     shape = (nc, p.n_el) + ((p.n_comp,) if p.n_comp > 1 else ())
