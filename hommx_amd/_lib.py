@@ -17,6 +17,7 @@ EXPORTED_SYMBOLS = (
     "hommx_device_count",
     "hommx_plan_create",
     "hommx_plan_destroy",
+    "hommx_plan_dim",
     "hommx_plan_num_elements",
     "hommx_plan_coef_components",
     "hommx_plan_tensor_size",
@@ -28,6 +29,11 @@ EXPORTED_SYMBOLS = (
     "hommx_solve_batch_two_phase_device",
     "hommx_solve_batch_separable",
     "hommx_solve_batch_separable_device",
+    "hommx_comm_init_all",
+    "hommx_comm_destroy",
+    "hommx_comm_size",
+    "hommx_allgather_field",
+    "hommx_solve_batch_multi",
     "hommx_calibrate_fp64_mfma",
     "hommx_last_error",
 )
@@ -126,6 +132,18 @@ def load():
     lib.hommx_solve_batch_separable.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.hommx_solve_batch_separable_device.restype = C.c_int
     lib.hommx_solve_batch_separable_device.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.hommx_plan_dim.restype = i32
+    lib.hommx_plan_dim.argtypes = [vp]
+    lib.hommx_comm_init_all.restype = C.c_int
+    lib.hommx_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
+    lib.hommx_comm_destroy.restype = C.c_int
+    lib.hommx_comm_destroy.argtypes = [vp]
+    lib.hommx_comm_size.restype = C.c_int
+    lib.hommx_comm_size.argtypes = [vp]
+    lib.hommx_allgather_field.restype = C.c_int
+    lib.hommx_allgather_field.argtypes = [vp, C.POINTER(vp), i64]
+    lib.hommx_solve_batch_multi.restype = C.c_int
+    lib.hommx_solve_batch_multi.argtypes = [vp, C.POINTER(vp), i64, vp, vp, vp, vp]
     lib.hommx_calibrate_fp64_mfma.restype = C.c_int
     lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
     lib.hommx_last_error.restype = C.c_char_p

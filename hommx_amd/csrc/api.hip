@@ -124,6 +124,10 @@ int hommx_plan_destroy(hommx_plan* p) {
   return HOMMX_OK;
 }
 
+// multi.hip reports its errors through the same thread-local message
+int hommx_set_error_(int code, const char* msg) { return fail(code, "%s", msg); }
+
+int32_t hommx_plan_dim(const hommx_plan* p) { return p ? p->desc.dim : 0; }
 int64_t hommx_plan_num_elements(const hommx_plan* p) { return p ? p->n_el : 0; }
 int32_t hommx_plan_coef_components(const hommx_plan* p) { return p ? p->n_comp : 0; }
 int32_t hommx_plan_tensor_size(const hommx_plan* p) { return p ? p->t : 0; }

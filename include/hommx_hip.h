@@ -31,6 +31,7 @@ extern "C" {
 #define HOMMX_EHIP (-2)     /* HIP runtime error (message in hommx_last_error) */
 #define HOMMX_ENODEV (-3)   /* no usable GPU */
 #define HOMMX_ENOMEM (-4)   /* device allocation failed */
+#define HOMMX_ERCCL (-5)    /* RCCL error (message in hommx_last_error) */
 
 /* problem kinds: which bilinear form of hmm.py the plan assembles */
 #define HOMMX_KIND_POISSON_SCALAR 0     /* hmm.py:644-667 (and :759-789 when M != NULL); coef[cell][el]            */
@@ -71,6 +72,7 @@ int hommx_plan_destroy(hommx_plan* plan);
 /* Shape queries: elements per micro mesh (2 n^2 / 6 n^3), coefficient doubles per element,
  * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), and the name of the
  * kernel family the plan dispatches to ("fused2d" / "blocked"). */
+int32_t hommx_plan_dim(const hommx_plan* plan);
 int64_t hommx_plan_num_elements(const hommx_plan* plan);
 int32_t hommx_plan_coef_components(const hommx_plan* plan);
 int32_t hommx_plan_tensor_size(const hommx_plan* plan);
@@ -148,6 +150,28 @@ int hommx_solve_batch_separable_device(hommx_plan* plan, int64_t n_cells, int32_
  * Runs on the blocked kernel family for every plan (the fused 2D kernel never forms the factors). */
 int hommx_solve_batch_correctors(hommx_plan* plan, int64_t n_cells, const double* coef, const double* M,
                                  double* A_eff, double* correctors, int32_t* info);
+
+/*
+ * Multi-GPU from ONE process: the macro cells are block-partitioned over the devices of a communicator --
+ * the reference's MPI partition of the cell loop (hmm.py:307-310) -- and ONE RCCL all-gather over xGMI returns the whole
+ * effective-tensor field (with the per-cell info flags riding in the same buffer) to every device, where the reference merges
+ * rank contributions in PETSc's assembly stash (hmm.py:325-330, :442).  RCCL is loaded lazily (dlopen) on the first call.
+ * Python callers that run one process per GPU use hommx_amd/dist.py instead.
+ *
+ *   hommx_comm_init_all     communicator over devs[0..ndev) (NULL: devices 0..ndev-1); one stream per device
+ *   hommx_allgather_field   in-place all-gather: d_field_per_dev[i] is a device buffer of ndev * count doubles on device i whose
+ *                           own shard already sits at offset i * count; returns after every device holds all shards
+ *   hommx_solve_batch_multi plans[i] = a plan created on device i of the communicator (same dim / n_micro / kind); host
+ *                           pointers as hommx_solve_batch.  Device i receives, solves and packs ONLY cells
+ *                           [i * ceil(n/ndev), (i+1) * ceil(n/ndev)); the field is all-gathered and copied out once.
+ */
+typedef struct hommx_comm hommx_comm;
+int hommx_comm_init_all(hommx_comm** out, int ndev, const int* devs);
+int hommx_comm_destroy(hommx_comm* comm);
+int hommx_comm_size(const hommx_comm* comm);
+int hommx_allgather_field(hommx_comm* comm, double* const* d_field_per_dev, int64_t count_per_dev);
+int hommx_solve_batch_multi(hommx_comm* comm, hommx_plan* const* plans, int64_t n_cells, const double* coef, const double* M,
+                            double* A_eff, int32_t* info);
 
 /* Calibration micro-benchmark: sustained fp64 MFMA rate (v_mfma_f64_16x16x4_f64, all CUs), in FLOP/s.
  * Used by bench.py to state the fp64 matrix peak next to the datasheet figure. */
