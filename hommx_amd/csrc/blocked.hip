@@ -838,6 +838,7 @@ struct BlockedWorkspace {
   bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
   bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
   bool small_fused = true;     // HOMMX_NO_SMALL_FUSED switches the LDS-resident kernel for b <= 64 off (A/B runs)
+  int small_waves = 0;         // HOMMX_SMALL_WAVES: waves per macro cell of that kernel (1 / 2 / 4; 0 = default)
   long long chunk = 0;
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
   double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
@@ -914,6 +915,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   ws->sparse_v1 = getenv("HOMMX_SPARSE_V1") != nullptr;
   ws->leaf32 = getenv("HOMMX_LEAF32") != nullptr;
   ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
+  if (const char* e = getenv("HOMMX_SMALL_WAVES")) ws->small_waves = atoi(e);
   *out = ws;
   return 0;
 }
@@ -1298,17 +1300,20 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
       int32_t* inf = d_info ? d_info + c0 : nullptr;
       const int nipc = G.ncode / 3;
       const int bp = G.b <= 32 ? 32 : G.b <= 48 ? 48 : 64;
-#define HOMMX_SF(BP_, BS_, NI_) hipLaunchKernelGGL((k_small_fused<BP_, BS_, NI_>), dim3((unsigned)nc), dim3((BP_ / 2) * (BP_ / 2)), 0, st, G, ws->Kst, ws->Brhs, ws->C0, o, inf, nc)
-#define HOMMX_SFK(BP_)                                                     \
+#define HOMMX_SF(BP_, BS_, NI_, NW_) hipLaunchKernelGGL((k_small_fused<BP_, BS_, NI_, NW_>), dim3((unsigned)nc), dim3(64 * NW_), 0, st, G, ws->Kst, ws->Brhs, ws->C0, o, inf, nc)
+#define HOMMX_SFK(BP_, NW_)                                                \
   do {                                                                     \
-    if (G.bs == 1 && nipc == 3) HOMMX_SF(BP_, 1, 3);                       \
-    else if (G.bs == 2) HOMMX_SF(BP_, 2, 3);                               \
-    else if (G.bs == 1) HOMMX_SF(BP_, 1, 9);                               \
-    else HOMMX_SF(BP_, 3, 9);                                              \
+    if (G.bs == 1 && nipc == 3) HOMMX_SF(BP_, 1, 3, NW_);                  \
+    else if (G.bs == 2) HOMMX_SF(BP_, 2, 3, NW_);                          \
+    else if (G.bs == 1) HOMMX_SF(BP_, 1, 9, NW_);                          \
+    else HOMMX_SF(BP_, 3, 9, NW_);                                         \
   } while (0)
-      if (bp == 32) HOMMX_SFK(32);
-      else if (bp == 48) HOMMX_SFK(48);
-      else HOMMX_SFK(64);
+      // waves per macro cell (HOMMX_SMALL_WAVES, dev knob; 0 = default): few waves per cell and many cells per CU beat one wave
+      // per tile -- the elimination is a chain of short phases, and a wave that waits at a barrier hides nobody's latency
+      const int nw = ws->small_waves > 0 ? ws->small_waves : (bp == 64 ? 4 : 2);  // measured: profiles/r02_kinds.txt
+      if (bp == 32) { if (nw == 1) HOMMX_SFK(32, 1); else if (nw == 2) HOMMX_SFK(32, 2); else HOMMX_SFK(32, 4); }
+      else if (bp == 48) { if (nw == 1) HOMMX_SFK(48, 1); else if (nw == 2) HOMMX_SFK(48, 2); else HOMMX_SFK(48, 4); }
+      else { if (nw == 1) HOMMX_SFK(64, 1); else if (nw == 2) HOMMX_SFK(64, 2); else HOMMX_SFK(64, 4); }
 #undef HOMMX_SFK
 #undef HOMMX_SF
       BTRY(hipGetLastError());

@@ -38,13 +38,16 @@ __device__ __forceinline__ int swz(int row, int col) {
   return row * BP + (col ^ ((row & 1) << 4));
 }
 
-template <int BP, int BSV, int NIPC>
-__global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo G, const double* __restrict__ Kst,
+template <int BP, int BSV, int NIPC, int NW>
+__global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __restrict__ Kst,
                                                                               const double* __restrict__ Brhs,
                                                                               const double* __restrict__ C0, double* __restrict__ out,
                                                                               int32_t* __restrict__ info, long long ncells) {
-  constexpr int NTL = BP / 16;        // 16 x 16 tiles per dimension: one wave per tile
-  constexpr int NTH = NTL * NTL * 64; // 256 / 576 / 1024 threads
+  constexpr int NTL = BP / 16;        // 16 x 16 tiles per dimension
+  constexpr int NTILE = NTL * NTL;
+  constexpr int NTH = NW * 64;        // NW waves per workgroup (= per macro cell); tiles are dealt round-robin to the waves
+  constexpr int TPW = (NTILE + NW - 1) / NW;  // tiles per wave
+  static_assert(NTH >= BP, "one thread per row of the plane block");
   constexpr int NE = NIPC * BSV;      // entries per row of E
   constexpr int LP = 8;               // pitch of the transposed load-row matrices (t <= 6 rows)
   constexpr int H2 = BP - 32;         // second diagonal block of the 2 x 2 block inverse (0 / 16 / 32)
@@ -70,11 +73,11 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
     const int code = ipc + (o + 1) * NIPC;
     return Kc[((long long)(code * BSV + al) * BSV + be) * nn + q + npl * pl];
   };
-  // Thread (ec, eg): ec = row of the plane block (node ec / BSV, component ec % BSV), eg = replica.  Each thread keeps the NE stencil
-  // entries of ITS row in registers, fetched from HBM a whole elimination step before they are used.
-  const int ec = tid % BP, eg = tid / BP;
-  constexpr int EG = NTH / BP;
-  const bool realrow = ec < b;
+  // Thread ec = tid < BP owns row ec of the plane block (node ec / BSV, component ec % BSV): it keeps the NE stencil entries of ITS
+  // row in registers, fetched from HBM a whole elimination step before they are used.
+  const int ec = tid;
+  const bool rowthread = tid < BP;
+  const bool realrow = rowthread && ec < b;
   int ex[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) ex[e] = 0;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
       for (int be = 0; be < BSV; ++be) ex[ipc * BSV + be] = qn * BSV + be;
     }
   }
-  if (eg == 0) {
+  if (rowthread) {
 #pragma unroll
     for (int e = 0; e < NE; ++e) ext[ec * NE + e] = ex[e];
   }
@@ -100,15 +103,18 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
         for (int be = 0; be < BSV; ++be) dst[ipc * BSV + be] = kst(pl, o, ec / BSV, ipc, ec % BSV, be);
     }
   };
-  // load rows: thread (pc = tid / LP, pm = tid % LP) holds P_pl[pm][pc]
-  const int pc = tid / LP, pm = tid % LP;
-  const bool pth = tid < BP * LP;
-  auto fetch_P = [&](int pl) {
-    return (pth && pc < b && pm < t) ? Bc[((long long)pm * BSV + pc % BSV) * nn + pc / BSV + npl * pl] : 0.0;
+  // load rows: entry idx = c * LP + m of the transposed (BP x LP) matrices; thread tid holds entries tid, tid + NTH, ...
+  constexpr int NPL = (BP * LP + NTH - 1) / NTH;
+  auto fetch_P = [&](double (&dst)[NPL], int pl) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int idx = tid + q * NTH, c = idx / LP, m = idx % LP;
+      dst[q] = (idx < BP * LP && c < b && m < t) ? Bc[((long long)m * BSV + c % BSV) * nn + c / BSV + npl * pl] : 0.0;
+    }
   };
   // dst (+)= rows held in registers (thread (ec, 0) owns row ec; several codes can hit one neighbour on tiny meshes: accumulate)
   auto add_rows = [&](double* dst, const double (&v)[NE], bool transposed, bool padIdentity) {
-    if (eg == 0) {
+    if (rowthread) {
       if (realrow) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -142,20 +148,22 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
     }
     return acc;
   };
-  // full BP x BP product, one tile per wave, fragments fetched up front:  OUT = A B  with A(i, k) = AT[k][i]
+  // full BP x BP product, fragments of a tile fetched up front:  OUT = A B  with A(i, k) = AT[k][i]
   auto mfma_full = [&](const double* AT, const double* Bm, double* OUT) {
-    const int ti = wave / NTL, tj = wave % NTL;
-    double af[BP / 4], bf[BP / 4];
+    for (int tile = wave; tile < NTILE; tile += NW) {
+      const int ti = tile / NTL, tj = tile % NTL;
+      double af[BP / 4], bf[BP / 4];
 #pragma unroll
-    for (int kk = 0; kk < BP / 4; ++kk) {
-      af[kk] = AT[swz<BP>(4 * kk + lk, 16 * ti + lj)];
-      bf[kk] = Bm[swz<BP>(4 * kk + lk, 16 * tj + lj)];
+      for (int kk = 0; kk < BP / 4; ++kk) {
+        af[kk] = AT[swz<BP>(4 * kk + lk, 16 * ti + lj)];
+        bf[kk] = Bm[swz<BP>(4 * kk + lk, 16 * tj + lj)];
+      }
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < BP / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) OUT[swz<BP>(16 * ti + 4 * r + lk, 16 * tj + lj)] = acc[r];
     }
-    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < BP / 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) OUT[swz<BP>(16 * ti + 4 * r + lk, 16 * tj + lj)] = acc[r];
     __syncthreads();
   };
   auto store_tile = [&](double* OUT, int r0, int c0, d4 acc) {
@@ -215,7 +223,7 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
       double* T1 = scratch;            // X^T: rows 0..31 (k of A), cols 0..H2-1   (BP-pitch view, rows 0..31)
       double* T2 = scratch + 32 * BP;  // X:   rows 0..H2-1, cols 0..31            (BP-pitch view, rows 32..)
       // X^T = Ai B^T (2 x HT tiles) and X = B Ai (HT x 2 tiles)
-      for (int tl = wave; tl < 4 * HT; tl += NTL * NTL) {
+      for (int tl = wave; tl < 4 * HT; tl += NW) {
         const bool second = tl >= 2 * HT;
         const int q = second ? tl - 2 * HT : tl;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
@@ -231,7 +239,7 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
       }
       __syncthreads();
       // Sc = C - X B^T:  Sc[i][j] -= sum_k X^T[k][i] M[k][32 + j]
-      for (int tl = wave; tl < HT * HT; tl += NTL * NTL) {
+      for (int tl = wave; tl < HT * HT; tl += NW) {
         const int ti = tl / HT, tj = tl % HT;
         d4 acc = load_tile(M, 32 + 16 * ti, 32 + 16 * tj);
         acc = tile_mm(acc, T1, false, 0, 16 * ti, M, false, 0, 32 + 16 * tj, 32, true);
@@ -241,7 +249,7 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
       if constexpr (H2 == 32) sweep32(M, 32, bad);
       else sweep16(M, 32, bad);
       // M21 = -Sci X (HT x 2 tiles), M12 = -X^T Sci (2 x HT tiles)
-      for (int tl = wave; tl < 4 * HT; tl += NTL * NTL) {
+      for (int tl = wave; tl < 4 * HT; tl += NW) {
         const bool second = tl >= 2 * HT;
         const int q = second ? tl - 2 * HT : tl;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
@@ -257,7 +265,7 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
       }
       __syncthreads();
       // M11 = Ai - X^T M21:  M11[i][j] -= sum_k X[k][i] M21[k][j]
-      for (int tl = wave; tl < 4; tl += NTL * NTL) {
+      for (int tl = wave; tl < 4; tl += NW) {
         const int ti = tl / 2, tj = tl % 2;
         d4 acc = load_tile(M, 16 * ti, 16 * tj);
         acc = tile_mm(acc, T2, false, 0, 16 * ti, M, false, 32, 16 * tj, H2, true);
@@ -269,12 +277,12 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
     __syncthreads();
   };
 
-  // ---- sparse products with E = K[(., plane pl), (., plane pl - 1)] ---------------------------------------------------------------------
+  // ---- sparse products with E = K[(., plane pl), (., plane pl - 1)]; its rows sit in LDS (evt / ext) during a step -------------------
   double ev[NE], dv[NE], el[NE];
-  // OUT[c][i] = alpha * sum_e E[c][e] IN[col(c, e)][i]      (OUT = alpha E IN).  Lanes run along i (a row of IN); E row c from LDS.
+  // OUT[c][i] = alpha * sum_e E[c][e] IN[col(c, e)][i]      (OUT = alpha E IN).  Lanes run along i (a row of IN).
   auto left_E = [&](const double* IN, double* OUT, double alpha) {
-    const int i = tid % BP;
-    for (int c = tid / BP; c < BP; c += EG) {
+    for (int idx = tid; idx < BP * BP; idx += NTH) {
+      const int c = idx / BP, i = idx % BP;
       double acc = 0.0;
 #pragma unroll
       for (int e = 0; e < NE; ++e) acc = fma(evt[c * NE + e], IN[swz<BP>(ext[c * NE + e], i)], acc);
@@ -282,34 +290,41 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
     }
     __syncthreads();
   };
-  // OUT[r][c] = alpha * sum_e IN[r][col(c, e)] E[c][e]      (OUT = alpha IN E^T).  Lanes run along c = ec: E row from registers.
+  // OUT[r][c] = alpha * sum_e IN[r][col(c, e)] E[c][e]      (OUT = alpha IN E^T).  Lanes run along c (gathers within row r of IN).
   auto right_Et = [&](const double* IN, double* OUT, double alpha) {
-    for (int r = eg; r < BP; r += EG) {
+    for (int idx = tid; idx < BP * BP; idx += NTH) {
+      const int r = idx / BP, c = idx % BP;
       double acc = 0.0;
 #pragma unroll
-      for (int e = 0; e < NE; ++e) acc = fma(IN[swz<BP>(r, ex[e])], ev[e], acc);
-      OUT[swz<BP>(r, ec)] = alpha * acc;
+      for (int e = 0; e < NE; ++e) acc = fma(IN[swz<BP>(r, ext[c * NE + e])], evt[c * NE + e], acc);
+      OUT[swz<BP>(r, c)] = alpha * acc;
     }
     __syncthreads();
   };
 
   // ---- init: every global load of the prologue is issued before the first use ------------------------------------------------------------
   if (tid == 0) badflag = 0;
-  const int sti = wave / NTL, stj = wave % NTL;  // this wave's tile of S_last (and of every full product)
-  d4 slacc;                                       // S_last tile, accumulator layout
-  d4 gacc = d4{0.0, 0.0, 0.0, 0.0};               // G (wave 0)
+  d4 slacc[TPW];                     // S_last tiles of this wave (tile = wave + NW q), accumulator layout
+  d4 gacc = d4{0.0, 0.0, 0.0, 0.0};  // G (wave 0)
   {
-    double d0[NE], w0[NE], dl[NE];
+    double d0[NE], w0[NE], dl[NE], p0[NPL], pl[NPL];
     fetch_row(d0, 0, 0);        // D_0
     fetch_row(w0, n - 1, +1);   // K[(., n-1), (., 0)]
     fetch_row(dl, n - 1, 0);    // D_{n-1}
     fetch_row(el, n - 1, -1);   // K[(., n-1), (., n-2)]: joins the arrow on the last step
-    const double p0 = fetch_P(0), pl = fetch_P(n - 1);
+    fetch_P(p0, 0);
+    fetch_P(pl, n - 1);
     zero(Sm); zero(WT); zero(VT);
     __syncthreads();
-    if (pth) { RT[tid] = p0; RlT[tid] = pl; }
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+      if (tid + q * NTH < BP * LP) { RT[tid + q * NTH] = p0[q]; RlT[tid + q * NTH] = pl[q]; }
     add_rows(VT, dl, false, true);   // S_last = D_{n-1} -> accumulators
-    slacc = load_tile(VT, 16 * sti, 16 * stj);
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      const int tile = wave + NW * q;
+      if (tile < NTILE) slacc[q] = load_tile(VT, 16 * (tile / NTL), 16 * (tile % NTL));
+    }
     add_rows(Sm, d0, false, true);   // S = D_0
     add_rows(WT, w0, true, false);   // W, stored transposed
   }
@@ -320,11 +335,11 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
 #endif
   for (int jp = 0; jp <= n - 2; ++jp) {
     const bool last = (jp == n - 2);
-    double pnext = 0.0;
+    double pnext[NPL];
     if (!last) {  // next plane's stencil rows: in flight during the whole step
       fetch_row(ev, jp + 1, -1);
       fetch_row(dv, jp + 1, 0);
-      pnext = fetch_P(jp + 1);
+      fetch_P(pnext, jp + 1);
     } else {
       add_rows(WT, el, true, false);  // the last plane couples to plane n-2 through E as well
     }
@@ -334,29 +349,33 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
     SF_T(1);
     mfma_full(Sm, WT, VT);    // V^T = Sinv W^T   (Sinv symmetric: A(i, k) = Sinv[k][i])
     // S_last -= V W^T  (A(i, k) = V[i][k] = VT[k][i], B(k, j) = W^T[k][j]); accumulators stay in registers
-    {
-      double af[BP / 4], bf[BP / 4];
 #pragma unroll
-      for (int kk = 0; kk < BP / 4; ++kk) {
-        af[kk] = -VT[swz<BP>(4 * kk + lk, 16 * sti + lj)];
-        bf[kk] = WT[swz<BP>(4 * kk + lk, 16 * stj + lj)];
+    for (int q = 0; q < TPW; ++q) {
+      const int tile = wave + NW * q;
+      if (tile < NTILE) {
+        const int sti = tile / NTL, stj = tile % NTL;
+        double af[BP / 4], bf[BP / 4];
+#pragma unroll
+        for (int kk = 0; kk < BP / 4; ++kk) {
+          af[kk] = -VT[swz<BP>(4 * kk + lk, 16 * sti + lj)];
+          bf[kk] = WT[swz<BP>(4 * kk + lk, 16 * stj + lj)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BP / 4; ++kk) slacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], slacc[q], 0, 0, 0);
       }
-#pragma unroll
-      for (int kk = 0; kk < BP / 4; ++kk) slacc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], slacc, 0, 0, 0);
     }
     SF_T(2);
     // load rows (transposed, pitch LP): Vr^T = Sinv R^T ; G += Vr R^T ; R_last^T -= W Vr^T
-    if (wave < NTL) {  // Vr^T[i][m] = sum_k Sinv[k][i] R^T[k][m]
+    for (int tr = wave; tr < NTL; tr += NW) {  // Vr^T[i][m] = sum_k Sinv[k][i] R^T[k][m]
       d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-      acc = tile_mm(acc, Sm, false, 0, 16 * wave, RT, true, 0, 0, BP, false);
+      acc = tile_mm(acc, Sm, false, 0, 16 * tr, RT, true, 0, 0, BP, false);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (lj < LP) VrT[(16 * wave + 4 * r + lk) * LP + lj] = acc[r];
+        if (lj < LP) VrT[(16 * tr + 4 * r + lk) * LP + lj] = acc[r];
     }
     __syncthreads();
     if (wave == 0) gacc = tile_mm(gacc, VrT, true, 0, 0, RT, true, 0, 0, BP, false);  // G[m][q] += sum_c Vr^T[c][m] R^T[c][q]
-    if (wave >= 1 && wave <= NTL) {  // R_last^T[r][m] -= sum_c W^T[c][r] Vr^T[c][m]   (NTL + 1 <= waves for every BP)
-      const int tr = wave - 1;
+    for (int tr = (wave + NW - 1) % NW; tr < NTL; tr += NW) {  // R_last^T[r][m] -= sum_c W^T[c][r] Vr^T[c][m]   (wave 0 last: it has G)
       d4 acc = d4{0.0, 0.0, 0.0, 0.0};
       acc = tile_mm(acc, WT, false, 0, 16 * tr, VrT, true, 0, 0, BP, false);
 #pragma unroll
@@ -366,17 +385,22 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
     __syncthreads();
     SF_T(3);
     if (!last) {
-      if (eg == 0) {
+      if (rowthread) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) evt[ec * NE + e] = ev[e];
       }
       __syncthreads();
       // R^T_next[c][m] = P_{j+1}[m][c] - sum_e E[c][e] Vr^T[col(c, e)][m]
-      if (pth) {
-        double acc = 0.0;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) acc = fma(evt[pc * NE + e], VrT[ext[pc * NE + e] * LP + pm], acc);
-        RT[tid] = pnext - acc;
+      for (int q = 0; q < NPL; ++q) {
+        const int idx = tid + q * NTH;
+        if (idx < BP * LP) {
+          const int c = idx / LP, m = idx % LP;
+          double acc = 0.0;
+#pragma unroll
+          for (int e = 0; e < NE; ++e) acc = fma(evt[c * NE + e], VrT[ext[c * NE + e] * LP + m], acc);
+          RT[idx] = pnext[q] - acc;
+        }
       }
       left_E(VT, WT, -1.0);   // W^T_next = -E V^T           (W_next = -V E^T)
       left_E(Sm, VT, 1.0);    // Z = E Sinv
@@ -387,7 +411,11 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
   }
 
   // ---- last plane: S_last out of the accumulators, gauge (drop the bs unknowns of the last node), inverse, loads ------------------------
-  store_tile(Sm, 16 * sti, 16 * stj, slacc);
+#pragma unroll
+  for (int q = 0; q < TPW; ++q) {
+    const int tile = wave + NW * q;
+    if (tile < NTILE) store_tile(Sm, 16 * (tile / NTL), 16 * (tile % NTL), slacc[q]);
+  }
   __syncthreads();
   for (int i = tid; i < BP * BSV; i += NTH) {
     const int x = i % BP, p = b - BSV + i / BP;
@@ -398,12 +426,12 @@ __global__ __launch_bounds__((BP / 16) * (BP / 16) * 64) void k_small_fused(Geo 
   __syncthreads();
   invert(Sm, VT, n);
   if (badflag && !firstbad) firstbad = badflag;
-  if (wave < NTL) {
+  for (int tr = wave; tr < NTL; tr += NW) {
     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-    acc = tile_mm(acc, Sm, false, 0, 16 * wave, RlT, true, 0, 0, BP, false);
+    acc = tile_mm(acc, Sm, false, 0, 16 * tr, RlT, true, 0, 0, BP, false);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (lj < LP) VrT[(16 * wave + 4 * r + lk) * LP + lj] = acc[r];
+      if (lj < LP) VrT[(16 * tr + 4 * r + lk) * LP + lj] = acc[r];
   }
   __syncthreads();
   if (wave == 0) {
