@@ -170,6 +170,18 @@ def main():
     if args.cpu_worker:
         return cpu_worker(args)
 
+    # stdout carries ONE JSON line: native libraries that chat on fd 1 (RCCL prints a version banner at communicator creation)
+    # are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(rec):
+        sys.stdout.flush()
+        os.dup2(_stdout_fd, 1)
+        print(json.dumps(rec), flush=True)
+        os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,7 +210,7 @@ def main():
         rec = run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellPlan, workloads, all_gather_field,
                      shard_range, stream)
         if rank == 0:
-            print(json.dumps(rec))
+            emit(rec)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -345,7 +357,7 @@ def main():
                 f"host cores available to this process: {avail}",
             }
             rec["effective_tensor_max_rel_err_vs_oracle"] = err
-        print(json.dumps(rec))
+        emit(rec)
     if use_dist:
         dist.destroy_process_group()
 

@@ -94,7 +94,10 @@ int hommx_solve_batch(hommx_plan* plan, int64_t n_cells, const double* coef, con
                       double* A_eff, int32_t* info);
 
 /* Same with DEVICE pointers, asynchronous on `stream` (a hipStream_t, NULL = default stream).
- * Nothing is retained after return; the caller synchronises the stream before reading A_eff. */
+ * No caller pointer is retained after return; the caller synchronises the stream before reading A_eff.  The blocked and
+ * small-block kernel families work out of scratch the PLAN owns (workspace, expanded coefficient stream): a plan is not
+ * thread-safe, and two calls on the same plan must not be in flight on different streams at once (distinct plans are
+ * independent; the fused 2D family keeps no scratch). */
 int hommx_solve_batch_device(hommx_plan* plan, int64_t n_cells, const double* d_coef, const double* d_M,
                              double* d_A_eff, int32_t* d_info, void* stream);
 

@@ -178,3 +178,55 @@ def test_constructor_checks():
                                  mesh.create_unit_square(4, 4), 0.1, lambda x: np.ones((2, 1)))
     with pytest.raises(ValueError):
         h._stratification(np.arange(2))
+
+
+def test_quadrature_degree_policy():
+    """Default policy of BaseHMM(quadrature_degree=None): what UFL would estimate for the reference's coefficient families
+    (hmm.py:190-198 + fem.form at :644-647)."""
+    from hommx_amd import workloads as W
+
+    msh, mic = mesh.create_unit_square(2, 2), mesh.create_unit_square(8, 8)
+    mk = lambda A, **kw: hmm.PoissonHMM(msh, A, lambda x: 1.0, mic, 0.01, **kw)
+    cells = np.arange(msh.num_cells)
+    # smooth coefficients of the reference's tests -> degree 3 (6-point rule)
+    for A in (lambda x, y: 1.0 / (2.0 + np.cos(2 * np.pi * y[0])), lambda x, y: 0.33 + 0.15 * (np.sin(2 * np.pi * x[0]) + np.sin(2 * np.pi * y[0]))):
+        h = mk(A)
+        coef, _ = h._element_means(cells)
+        assert h.quadrature_degree_used == 3
+        assert np.allclose(coef[0], O.sample_coefficient(A, msh.cell_midpoints()[0], 2, 8, 3), rtol=0, atol=1e-15)
+    # conditionals between constants -> centroid rule, also when the interface cuts through elements (wrapped disc, inclusion.py:107-118)
+    for A in (lambda x, y: np.where(np.cos(2 * np.pi * y[0]) < 0, 5.0, 0.05), lambda x, y: np.where(W.wrapped_disc(y[0], y[1]), 0.001 * (1 + 9 * x[0]), 0.1)):
+        h = mk(A)
+        coef, _ = h._element_means(cells)
+        assert h.quadrature_degree_used == 0
+        assert np.array_equal(coef[1], O.sample_coefficient(A, msh.cell_midpoints()[1], 2, 8, 0))
+    # an explicit degree wins; TwoPhase is piecewise constant by construction
+    assert mk(lambda x, y: 1.0 + y[0], quadrature_degree=2)._element_means(cells) is not None
+    tp = hmm.TwoPhase(lambda y: y[0] < 0.5, lambda x: 2.0, lambda x: 1.0)
+    assert mk(tp).quadrature_degree_used == 0
+    with pytest.raises(ValueError):
+        mk(tp, quadrature_degree=3)
+
+
+def test_separable_host_stream_and_asymmetric_matrix_coefficient():
+    """hmm.Separable: the documented host equivalent of the device sampler agrees with the generic callable path to rounding;
+    a non-symmetric matrix-valued A is refused (the Schur form equals the reference's energy functional only for symmetric A)."""
+    mic = mesh.create_unit_square(6, 6)
+    bary, w = hmm.micro_quadrature(2, 3)
+    yq = np.einsum("qa,eak->eqk", bary, mic.cell_vertices())
+    c = np.array([[0.2, 0.3, 0.0], [0.7, 0.1, 0.0], [0.5, 0.9, 0.0]])
+    for fam in ("affine", "reciprocal"):
+        co = hmm.Separable(fam, lambda x: 2.0 + x[0], lambda x: 0.5 + 0.1 * x[1], lambda y: np.cos(2 * np.pi * y[0]) * np.sin(2 * np.pi * y[1]))
+        stream = co.host_stream(co.params(c), co.table(yq, w), w)
+        gen = np.stack([np.tensordot(w, np.asarray(co(c[k], yq.reshape(-1, 2).T)).reshape(yq.shape[:2]), axes=([0], [1])) for k in range(3)])
+        assert np.abs(stream - gen).max() < 1e-14
+    with pytest.raises(ValueError):
+        hmm.Separable("cubic", None, None, None)
+    msh = mesh.create_unit_square(2, 2)
+    Aasym = lambda x, y: np.broadcast_to(np.array([[2.0, 0.5], [0.1, 1.0]]), (y.shape[1], 2, 2))
+    h = hmm.PoissonHMM(msh, Aasym, lambda x: 1.0, mic, 0.01)
+    with pytest.raises(ValueError, match="symmetric"):
+        h._element_means(np.arange(msh.num_cells))
+    Asym = lambda x, y: np.broadcast_to(np.array([[2.0, 0.3], [0.3, 1.0]]), (y.shape[1], 2, 2))
+    coef, kind = hmm.PoissonHMM(msh, Asym, lambda x: 1.0, mic, 0.01)._element_means(np.arange(msh.num_cells))
+    assert kind == "poisson_matrix" and coef.shape == (8, 72, 3)
