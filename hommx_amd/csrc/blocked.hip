@@ -229,32 +229,43 @@ __global__ __launch_bounds__(128) void k_assemble(Geo G, const double* __restric
   }
 }
 
-// C0[cell][t][t] = sum_e vol Cv_e ; one block per cell.  Fixed summation order (thread-strided partial sums, wave butterfly,
-// four wave totals added in order): bitwise reproducible.
+// C0[cell][t][t] = sum_e vol Cv_e ; one block per cell.  Compile-time (dim, kind): the t x t partial sums stay in registers.
+// Fixed summation order (thread-strided partial sums, wave butterfly, four wave totals added in order): bitwise reproducible.
+template <int D, int KIND>
 __global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ coef, double* __restrict__ C0) {
+  constexpr bool EL = KIND >= HOMMX_KIND_ELASTICITY_ISO;
+  constexpr int T = EL ? D * (D + 1) / 2 : D, TT = T * T;
+  constexpr int NCOMP = KIND == HOMMX_KIND_POISSON_SCALAR ? 1
+                        : KIND == HOMMX_KIND_POISSON_MATRIX ? D * (D + 1) / 2
+                        : KIND == HOMMX_KIND_ELASTICITY_ISO ? 2
+                                                            : T * (T + 1) / 2;
   const long long cell = blockIdx.x;
-  const int t = G.t, tt = t * t;
-  double acc[36];
-  for (int i = 0; i < tt; ++i) acc[i] = 0.0;
-  const double* ccell = coef + cell * (long long)G.n_el * G.ncomp;
+  double acc[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) acc[i] = 0.0;
+  const double* ccell = coef + cell * (long long)G.n_el * NCOMP;
   for (int e = threadIdx.x; e < G.n_el; e += 256) {
-    double Cv[36];
-    element_matrix(G, ccell + (long long)e * G.ncomp, Cv);
-    for (int i = 0; i < tt; ++i) acc[i] += Cv[i];
+    double cval[NCOMP], Cv[TT];
+#pragma unroll
+    for (int q = 0; q < NCOMP; ++q) cval[q] = ccell[(long long)e * NCOMP + q];
+    element_matrix_ct<D, KIND, T>(cval, Cv);
+#pragma unroll
+    for (int i = 0; i < TT; ++i) acc[i] += Cv[i];
   }
-  __shared__ double red[4][36];
+  __shared__ double red[4][TT];
   double vol = 1.0;
-  for (int k = 0; k < G.dim; ++k) vol /= G.n;
-  vol /= (G.dim == 2 ? 2.0 : 6.0);
+  for (int k = 0; k < D; ++k) vol /= G.n;
+  vol /= (D == 2 ? 2.0 : 6.0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = 0; i < tt; ++i) {
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
     double v = acc[i];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) red[wave][i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < tt) C0[cell * tt + threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * vol;
+  if (threadIdx.x < TT) C0[cell * TT + threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * vol;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1293,7 +1304,15 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
       }
 #undef HOMMX_ASM
     }
-    hipLaunchKernelGGL(k_c0, dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0);
+    {
+#define HOMMX_C0(D_, K_) hipLaunchKernelGGL((k_c0<D_, K_>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0)
+      if (G.dim == 2) {
+        if (G.kind == 0) HOMMX_C0(2, 0); else if (G.kind == 1) HOMMX_C0(2, 1); else if (G.kind == 2) HOMMX_C0(2, 2); else HOMMX_C0(2, 3);
+      } else {
+        if (G.kind == 0) HOMMX_C0(3, 0); else if (G.kind == 1) HOMMX_C0(3, 1); else if (G.kind == 2) HOMMX_C0(3, 2); else HOMMX_C0(3, 3);
+      }
+#undef HOMMX_C0
+    }
     if (G.b <= 64 && !d_corr && ws->small_fused) {
       // small plane blocks: the whole elimination in ONE launch, matrices in LDS (small_fused.h)
       double* o = d_out + c0 * G.t * G.t;

@@ -12,10 +12,11 @@
 //     V^T  = Sinv W^T      v_mfma_f64_16x16x4_f64: the arrow is kept transposed so that every fragment is a ROW read from LDS
 //     S_last -= V W^T      (rows k, k+1 of a fragment on disjoint bank halves: XOR swizzle, or pitch 48)
 //     load rows            kept transposed as well (BP x 8): Vr^T = Sinv R^T, G += Vr R^T, R_last^T -= W Vr^T on the matrix cores
-//     W^T_next = -E V^T ;  S_next = D_{j+1} - (E Sinv) E^T ;  R^T_next = P^T - E Vr^T          sparse, E from the node stencil
+//     W^T_next = -E V^T ;  S_next = D_{j+1} - (E Sinv) E^T ;  R^T_next = P^T - E Vr^T          E (<= 27 entries per row, from the node
+//                          stencil) is scattered DENSE into the buffer the dead arrow leaves free, and the three products run on the
+//                          matrix cores as well: gather loops over LDS cost 3x more here than the zeros cost the MFMAs
 //
-// The stencil rows a step needs are fetched from HBM one whole step ahead (registers); lanes always run along a matrix ROW when
-// they gather from LDS (a column walk puts 64 lanes on one bank).  Correctors are not formed here: hommx_solve_batch_correctors
+// The stencil rows a step needs are fetched from HBM one whole step ahead (registers).  Correctors are not formed here: hommx_solve_batch_correctors
 // stays on the HBM-resident route.
 #pragma once
 
@@ -55,8 +56,6 @@ __global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __
   __shared__ double WT[BP * BP];      // W^T
   __shared__ double VT[BP * BP];      // V^T, Z = E Sinv; scratch of the block inverse
   __shared__ double RT[BP * LP], RlT[BP * LP], VrT[BP * LP];  // R^T, R_last^T, Vr^T
-  __shared__ double evt[BP * NE];     // E rows of the current step (values) ...
-  __shared__ int ext[BP * NE];        // ... and their column indices (the same in every plane)
   __shared__ double ubuf[4 * 32];     // pivot-row buffers of the sweeps
   __shared__ int badflag;
 
@@ -88,10 +87,6 @@ __global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __
 #pragma unroll
       for (int be = 0; be < BSV; ++be) ex[ipc * BSV + be] = qn * BSV + be;
     }
-  }
-  if (rowthread) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) ext[ec * NE + e] = ex[e];
   }
   auto fetch_row = [&](double (&dst)[NE], int pl, int o) {  // row ec of K[(., pl), (., pl + o)]
 #pragma unroll
@@ -277,29 +272,26 @@ __global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __
     __syncthreads();
   };
 
-  // ---- sparse products with E = K[(., plane pl), (., plane pl - 1)]; its rows sit in LDS (evt / ext) during a step -------------------
+  // ---- coupling E = K[(., plane pl), (., plane pl - 1)]: row ec in ev[] (registers), scattered dense (transposed) for the products ----
   double ev[NE], dv[NE], el[NE];
-  // OUT[c][i] = alpha * sum_e E[c][e] IN[col(c, e)][i]      (OUT = alpha E IN).  Lanes run along i (a row of IN).
-  auto left_E = [&](const double* IN, double* OUT, double alpha) {
-    for (int idx = tid; idx < BP * BP; idx += NTH) {
-      const int c = idx / BP, i = idx % BP;
-      double acc = 0.0;
+  // full product with the result left in this wave's accumulator tiles:  acc[q] = -(A B)(tile wave + NW q),  A(i, k) = AT[k][i]
+  auto mfma_full_regs = [&](const double* AT, const double* Bm, d4 (&acc)[TPW]) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) acc = fma(evt[c * NE + e], IN[swz<BP>(ext[c * NE + e], i)], acc);
-      OUT[swz<BP>(c, i)] = alpha * acc;
-    }
-    __syncthreads();
-  };
-  // OUT[r][c] = alpha * sum_e IN[r][col(c, e)] E[c][e]      (OUT = alpha IN E^T).  Lanes run along c (gathers within row r of IN).
-  auto right_Et = [&](const double* IN, double* OUT, double alpha) {
-    for (int idx = tid; idx < BP * BP; idx += NTH) {
-      const int r = idx / BP, c = idx % BP;
-      double acc = 0.0;
+    for (int q = 0; q < TPW; ++q) {
+      const int tile = wave + NW * q;
+      acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+      if (tile < NTILE) {
+        const int ti = tile / NTL, tj = tile % NTL;
+        double af[BP / 4], bf[BP / 4];
 #pragma unroll
-      for (int e = 0; e < NE; ++e) acc = fma(IN[swz<BP>(r, ext[c * NE + e])], evt[c * NE + e], acc);
-      OUT[swz<BP>(r, c)] = alpha * acc;
+        for (int kk = 0; kk < BP / 4; ++kk) {
+          af[kk] = -AT[swz<BP>(4 * kk + lk, 16 * ti + lj)];
+          bf[kk] = Bm[swz<BP>(4 * kk + lk, 16 * tj + lj)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BP / 4; ++kk) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk], acc[q], 0, 0, 0);
+      }
     }
-    __syncthreads();
   };
 
   // ---- init: every global load of the prologue is issued before the first use ------------------------------------------------------------
@@ -385,27 +377,40 @@ __global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __
     __syncthreads();
     SF_T(3);
     if (!last) {
-      if (rowthread) {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) evt[ec * NE + e] = ev[e];
-      }
+      // E^T dense into the arrow's buffer (W is dead: R_last has used it)
+      zero(WT);
       __syncthreads();
-      // R^T_next[c][m] = P_{j+1}[m][c] - sum_e E[c][e] Vr^T[col(c, e)][m]
+      add_rows(WT, ev, true, false);
+      // R^T_next = P^T_{j+1} - E Vr^T:  (E Vr^T)[c][m] = sum_k E^T[k][c] Vr^T[k][m]
+      for (int tr = wave; tr < NTL; tr += NW) {
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        acc = tile_mm(acc, WT, false, 0, 16 * tr, VrT, true, 0, 0, BP, true);
 #pragma unroll
-      for (int q = 0; q < NPL; ++q) {
-        const int idx = tid + q * NTH;
-        if (idx < BP * LP) {
-          const int c = idx / LP, m = idx % LP;
-          double acc = 0.0;
+        for (int r = 0; r < 4; ++r)
+          if (lj < LP) RT[(16 * tr + 4 * r + lk) * LP + lj] = acc[r];  // -E Vr^T; P^T is added below by the threads that fetched it
+      }
+      d4 wnext[TPW];
+      mfma_full_regs(WT, VT, wnext);   // W^T_next = -E V^T  (A(i, k) = E[i][k] = E^T[k][i]) -> registers: its buffer still holds E^T
+      __syncthreads();                 // V^T and R^T tiles consumed / written
 #pragma unroll
-          for (int e = 0; e < NE; ++e) acc = fma(evt[c * NE + e], VrT[ext[c * NE + e] * LP + m], acc);
-          RT[idx] = pnext[q] - acc;
+      for (int q = 0; q < NPL; ++q)
+        if (tid + q * NTH < BP * LP) RT[tid + q * NTH] += pnext[q];
+      mfma_full(Sm, WT, VT);           // Z^T = Sinv E^T   (Sinv symmetric)
+      {                                // S_next = -Z E^T ...:  A(i, k) = Z[i][k] = Z^T[k][i], B(k, j) = E^T[k][j]
+        d4 sn[TPW];
+        mfma_full_regs(VT, WT, sn);
+        __syncthreads();               // E^T consumed: the arrow's buffer is free again
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+          const int tile = wave + NW * q;
+          if (tile < NTILE) {
+            store_tile(Sm, 16 * (tile / NTL), 16 * (tile % NTL), sn[q]);
+            store_tile(WT, 16 * (tile / NTL), 16 * (tile % NTL), wnext[q]);
+          }
         }
       }
-      left_E(VT, WT, -1.0);   // W^T_next = -E V^T           (W_next = -V E^T)
-      left_E(Sm, VT, 1.0);    // Z = E Sinv
-      right_Et(VT, Sm, -1.0); // S_next = -Z E^T ...
-      add_rows(Sm, dv, false, true);  //     ... + D_{j+1}
+      __syncthreads();
+      add_rows(Sm, dv, false, true);   //     ... + D_{j+1}
       SF_T(4);
     }
   }
