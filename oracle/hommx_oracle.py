@@ -23,6 +23,9 @@ plus closed-form laminate results (see tests/test_oracle_kat.py).  Anything beyo
 sets, which are recalled from DOLFINx 0.9 / Basix 0.9 public sources and marked
 "3P-memory" below) is **parity unpinned** by the reference and pinned only by this file.
 
+A second restatement, independent in code and in algorithm (closed-form periodic stencil, dense block-cyclic elimination, Schur
+form), lives in ``oracle/hommx_oracle_c.c`` for the 2D Poisson path; ``tests/test_oracle_c.py`` holds the two against each other.
+
 Every function cites the reference lines (``/root/reference/src/hommx/...``) it restates.
 """
 
