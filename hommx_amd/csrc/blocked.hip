@@ -22,19 +22,12 @@
 #include <string>
 
 #include "../../include/hommx_hip.h"
+#include "geo.h"
 #include "kernels.h"
 #include "sweep.h"
 
 namespace hommx {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-struct Geo {
-  int dim, n, bs, t, kind, ncomp;
-  int nn, npl, b, Bp, nsub, ncode, n_el;
-  int voff[6][4][3];     // corner offset of local vertex a of sub-element s
-  double grad[6][4][3];  // gradient of its P1 basis function on the unit-size cell (h = 1)
-};
 
 static thread_local std::string g_berr;
 const char* blocked_last_error() { return g_berr.c_str(); }
@@ -271,18 +264,6 @@ __global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ co
 // ---------------------------------------------------------------------------------------------------------------
 // stencil <-> dense plane blocks
 // ---------------------------------------------------------------------------------------------------------------
-
-// in-plane neighbour q' of in-plane node q for in-plane code ipc
-__device__ __forceinline__ int plane_neighbour(const Geo& G, int q, int ipc) {
-  const int n = G.n;
-  if (G.dim == 2) {
-    const int o = ipc - 1;
-    return (q + o + n) % n;
-  }
-  const int ox = ipc % 3 - 1, oy = ipc / 3 - 1;
-  const int i = (q % n + ox + n) % n, j = (q / n + oy + n) % n;
-  return i + n * j;
-}
 
 // dst[r][c] += K[(r in plane rowPlane), (c in plane rowPlane + olast)]; optional identity on the padding diagonal
 __global__ void k_scatter_plane(Geo G, const double* __restrict__ Kst, double* __restrict__ dst, long long ncells,
@@ -834,10 +815,6 @@ hipError_t launch_expand_separable(CoefSource src, const double* d_params, doubl
   return hipGetLastError();
 }
 
-}  // namespace hommx
-#include "small_fused.h"
-namespace hommx {
-
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------
@@ -1317,24 +1294,9 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
       // small plane blocks: the whole elimination in ONE launch, matrices in LDS (small_fused.h)
       double* o = d_out + c0 * G.t * G.t;
       int32_t* inf = d_info ? d_info + c0 : nullptr;
-      const int nipc = G.ncode / 3;
-      const int bp = G.b <= 32 ? 32 : G.b <= 48 ? 48 : 64;
-#define HOMMX_SF(BP_, BS_, NI_, NW_) hipLaunchKernelGGL((k_small_fused<BP_, BS_, NI_, NW_>), dim3((unsigned)nc), dim3(64 * NW_), 0, st, G, ws->Kst, ws->Brhs, ws->C0, o, inf, nc)
-#define HOMMX_SFK(BP_, NW_)                                                \
-  do {                                                                     \
-    if (G.bs == 1 && nipc == 3) HOMMX_SF(BP_, 1, 3, NW_);                  \
-    else if (G.bs == 2) HOMMX_SF(BP_, 2, 3, NW_);                          \
-    else if (G.bs == 1) HOMMX_SF(BP_, 1, 9, NW_);                          \
-    else HOMMX_SF(BP_, 3, 9, NW_);                                         \
-  } while (0)
-      // waves per macro cell (HOMMX_SMALL_WAVES, dev knob; 0 = default): few waves per cell and many cells per CU beat one wave
-      // per tile -- the elimination is a chain of short phases, and a wave that waits at a barrier hides nobody's latency
-      const int nw = ws->small_waves > 0 ? ws->small_waves : (bp == 64 ? 4 : 2);  // measured: profiles/r02_kinds.txt
-      if (bp == 32) { if (nw == 1) HOMMX_SFK(32, 1); else if (nw == 2) HOMMX_SFK(32, 2); else HOMMX_SFK(32, 4); }
-      else if (bp == 48) { if (nw == 1) HOMMX_SFK(48, 1); else if (nw == 2) HOMMX_SFK(48, 2); else HOMMX_SFK(48, 4); }
-      else { if (nw == 1) HOMMX_SFK(64, 1); else if (nw == 2) HOMMX_SFK(64, 2); else HOMMX_SFK(64, 4); }
-#undef HOMMX_SFK
-#undef HOMMX_SF
+      // waves per macro cell (HOMMX_SMALL_WAVES, dev knob; 0 = default: 2 for b <= 48, 4 for b = 64, profiles/r02_kinds.txt): few
+      // waves per cell and many cells per CU beat one wave per tile -- the elimination is a chain of short phases
+      BTRY(launch_small_fused(G, ws->Kst, ws->Brhs, ws->C0, o, inf, nc, ws->small_waves, st));
       BTRY(hipGetLastError());
       continue;
     }

@@ -1,4 +1,4 @@
-// small_fused.h -- LDS-resident fused elimination for SMALL plane blocks (b = bs * n^(d-1) <= 64), included by blocked.hip.
+// small_fused.h -- LDS-resident fused elimination for SMALL plane blocks (b = bs * n^(d-1) <= 64), compiled in small.hip.
 //
 // The blocked family spends ~2,700 launches and six HBM-resident b x b matrices per chunk; for the sizes of the reference's own
 // tests -- 2D elasticity on 10 x 10 micro cells (b = 20: test_integration_linear_elasticity.py:62-171), 3D Poisson on 6^3
@@ -20,6 +20,7 @@
 // stays on the HBM-resident route.
 #pragma once
 
+#include "geo.h"
 #include "sweep_acc.h"
 
 namespace hommx {

@@ -49,7 +49,7 @@ extern "C" {
  *   HOMMX_LEAF32           any value: 32x32 leaves only in the recursive block inverse
  *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the LDS-resident one
- *   HOMMX_SMALL_WAVES      waves per macro cell of the LDS-resident small-block kernel (1 / 2 / 4)                            */
+ *   HOMMX_SMALL_WAVES      waves per macro cell of the LDS-resident small-block kernel (2 / 4)                                */
 
 typedef struct hommx_plan hommx_plan;
 

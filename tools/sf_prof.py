@@ -1,5 +1,5 @@
 """Dev tool: per-phase clock counts (100 MHz wall clock) of k_small_fused for cell 0, from a library built with -DHOMMX_SF_PROF:
-    hipcc -DHOMMX_SF_PROF ... -c hommx_amd/csrc/blocked.hip -o tools/bin/blocked_prof.o ; link into tools/bin/lib_sfprof.so
+    hipcc -DHOMMX_SF_PROF ... -c hommx_amd/csrc/small.hip -o tools/bin/small_prof.o ; link it instead of small.o into tools/bin/lib_sfprof.so
     HOMMX_LIB=$PWD/tools/bin/lib_sfprof.so python tools/sf_prof.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
