@@ -40,8 +40,9 @@ __device__ __forceinline__ int swz(int row, int col) {
   return row * BP + (col ^ ((row & 1) << 4));
 }
 
+// waves per SIMD the register budget has to admit: BP = 32 is LDS-bound at 5 cells per CU (28 KB each), i.e. 3 waves on some SIMDs
 template <int BP, int BSV, int NIPC, int NW>
-__global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __restrict__ Kst,
+__global__ __launch_bounds__(NW * 64, (BP == 32 ? (NW == 2 ? 3 : 5) : 1)) void k_small_fused(Geo G, const double* __restrict__ Kst,
                                                                               const double* __restrict__ Brhs,
                                                                               const double* __restrict__ C0, double* __restrict__ out,
                                                                               int32_t* __restrict__ info, long long ncells) {
