@@ -222,6 +222,119 @@ __global__ __launch_bounds__(128) void k_assemble(Geo G, const double* __restric
   }
 }
 
+// Corner offsets of the sub-elements as compile-time constants (the same tables fill_tables() puts into Geo::voff): with them the
+// stencil slot `code` of every (sub-element, vertex, vertex) triple is a constant and the node's stencil row can stay in registers.
+template <int D>
+__host__ __device__ constexpr int voff_ct(int s, int a, int k) {
+  constexpr int tri[2][3][2] = {{{0, 0}, {1, 0}, {1, 1}}, {{0, 0}, {0, 1}, {1, 1}}};
+  constexpr int vb[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+  constexpr int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 7, 5}, {0, 5, 7, 4}, {0, 3, 2, 7}, {0, 6, 4, 7}, {0, 2, 6, 7}};
+  return D == 2 ? tri[s][a][k] : vb[tet[s][a]][k];
+}
+template <int D>
+__host__ __device__ constexpr int code_ct(int s, int a, int b) {
+  int cd = 0, p3 = 1;
+  for (int k = 0; k < D; ++k, p3 *= 3) cd += (voff_ct<D>(s, b, k) - voff_ct<D>(s, a, k) + 1) * p3;
+  return cd;
+}
+
+// K1 with the node's whole stencil row (NCODE x bs x bs) and load entries accumulated in REGISTERS and written once -- no
+// read-modify-write chains through L2, no memset of the stencil array.  Same arithmetic, same order of the 24 / 6 incident
+// (sub-element, vertex) pairs as k_assemble: bitwise the same numbers.  For bs^2 * 3^d <= 36 (scalar kinds, 2D elasticity).
+template <int D, int KIND>
+__global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __restrict__ coef, const double* __restrict__ Mmat,
+                                                      double* __restrict__ Kst, double* __restrict__ Brhs, long long ncells) {
+  constexpr bool EL = KIND >= HOMMX_KIND_ELASTICITY_ISO;
+  constexpr int BSV = EL ? D : 1, T = EL ? D * (D + 1) / 2 : D, NV = D + 1, NSUB = (D == 2) ? 2 : 6, NCODE = (D == 2) ? 9 : 27;
+  constexpr int NCOMP = KIND == HOMMX_KIND_POISSON_SCALAR ? 1
+                        : KIND == HOMMX_KIND_POISSON_MATRIX ? D * (D + 1) / 2
+                        : KIND == HOMMX_KIND_ELASTICITY_ISO ? 2
+                                                            : T * (T + 1) / 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ncells * G.nn) return;
+  const long long cell = idx / G.nn;
+  const int node = (int)(idx % G.nn);
+  const int n = G.n;
+  int pc[3] = {node % n, (node / n) % n, D == 3 ? node / (n * n) : 0};
+  double M[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) M[i][j] = Mmat ? Mmat[cell * D * D + i * D + j] : (i == j ? 1.0 : 0.0);
+  double vol = 1.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vol /= n;
+  vol /= (D == 2 ? 2.0 : 6.0);
+  const double* ccell = coef + cell * (long long)G.n_el * NCOMP;
+  double Kacc[NCODE * BSV * BSV], Bacc[T * BSV];
+#pragma unroll
+  for (int i = 0; i < NCODE * BSV * BSV; ++i) Kacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < T * BSV; ++i) Bacc[i] = 0.0;
+#pragma unroll
+  for (int s = 0; s < NSUB; ++s) {
+#pragma unroll
+    for (int a = 0; a < NV; ++a) {
+      int cc[3] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        int v = pc[k] - voff_ct<D>(s, a, k);
+        cc[k] = v < 0 ? v + n : v;
+      }
+      const long long e = (long long)NSUB * (cc[0] + n * (cc[1] + (long long)n * cc[2])) + s;
+      double cval[NCOMP];
+#pragma unroll
+      for (int q = 0; q < NCOMP; ++q) cval[q] = ccell[e * NCOMP + q];
+      double Cv[T * T];
+      element_matrix_ct<D, KIND, T>(cval, Cv);
+      double gt[NV][D];  // g~_b = M (n grad_b)
+#pragma unroll
+      for (int b = 0; b < NV; ++b)
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) acc += M[i][k] * G.grad[s][b][k];
+          gt[b][i] = acc * n;
+        }
+#pragma unroll
+      for (int al = 0; al < BSV; ++al) {
+        double w[T], y[T];
+        strain_weights_ct<D, BSV, T>(gt[a], al, w);
+#pragma unroll
+        for (int m = 0; m < T; ++m) {
+          double acc = 0.0;
+#pragma unroll
+          for (int q = 0; q < T; ++q) acc += Cv[m * T + q] * w[q];
+          y[m] = vol * acc;
+        }
+#pragma unroll
+        for (int m = 0; m < T; ++m) Bacc[m * BSV + al] -= y[m];
+#pragma unroll
+        for (int b = 0; b < NV; ++b) {
+          constexpr int dummy = 0;
+          (void)dummy;
+#pragma unroll
+          for (int be = 0; be < BSV; ++be) {
+            double wb[T];
+            strain_weights_ct<D, BSV, T>(gt[b], be, wb);
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < T; ++m) acc += y[m] * wb[m];
+            Kacc[(code_ct<D>(s, a, b) * BSV + al) * BSV + be] += acc;
+          }
+        }
+      }
+    }
+  }
+  double* Kc = Kst + cell * (long long)NCODE * BSV * BSV * G.nn;
+  double* Bc = Brhs + cell * (long long)T * BSV * G.nn;
+#pragma unroll
+  for (int i = 0; i < NCODE * BSV * BSV; ++i) Kc[(long long)i * G.nn + node] = Kacc[i];
+#pragma unroll
+  for (int i = 0; i < T * BSV; ++i) Bc[(long long)i * G.nn + node] = Bacc[i];
+}
+
 // C0[cell][t][t] = sum_e vol Cv_e ; one block per cell.  Compile-time (dim, kind): the t x t partial sums stay in registers.
 // Fixed summation order (thread-strided partial sums, wave butterfly, four wave totals added in order): bitwise reproducible.
 template <int D, int KIND>
@@ -1268,17 +1381,21 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
     const double* coef = d_coef + c0 * G.n_el * G.ncomp;
     const double* Mm = d_M ? d_M + c0 * G.dim * G.dim : nullptr;
-    // ---- K1
-    BTRY(hipMemsetAsync(ws->Kst, 0, 8ll * nc * G.ncode * G.bs * G.bs * G.nn, st));
-    BTRY(hipMemsetAsync(ws->Brhs, 0, 8ll * nc * G.t * G.bs * G.nn, st));
+    // ---- K1: stencil row in registers where it fits (scalar kinds, 2D elasticity: also no memset), else read-modify-write
     {
       dim3 ag(nblk(nc * G.nn, 128)), ab(128);
+#define HOMMX_ASMR(D_, K_) hipLaunchKernelGGL((k_assemble_reg<D_, K_>), ag, ab, 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc)
 #define HOMMX_ASM(D_, K_) hipLaunchKernelGGL((k_assemble<D_, K_>), ag, ab, 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc)
       if (G.dim == 2) {
-        if (G.kind == 0) HOMMX_ASM(2, 0); else if (G.kind == 1) HOMMX_ASM(2, 1); else if (G.kind == 2) HOMMX_ASM(2, 2); else HOMMX_ASM(2, 3);
+        if (G.kind == 0) HOMMX_ASMR(2, 0); else if (G.kind == 1) HOMMX_ASMR(2, 1); else if (G.kind == 2) HOMMX_ASMR(2, 2); else HOMMX_ASMR(2, 3);
+      } else if (G.kind <= 1) {
+        if (G.kind == 0) HOMMX_ASMR(3, 0); else HOMMX_ASMR(3, 1);
       } else {
-        if (G.kind == 0) HOMMX_ASM(3, 0); else if (G.kind == 1) HOMMX_ASM(3, 1); else if (G.kind == 2) HOMMX_ASM(3, 2); else HOMMX_ASM(3, 3);
+        BTRY(hipMemsetAsync(ws->Kst, 0, 8ll * nc * G.ncode * G.bs * G.bs * G.nn, st));
+        BTRY(hipMemsetAsync(ws->Brhs, 0, 8ll * nc * G.t * G.bs * G.nn, st));
+        if (G.kind == 2) HOMMX_ASM(3, 2); else HOMMX_ASM(3, 3);
       }
+#undef HOMMX_ASMR
 #undef HOMMX_ASM
     }
     {

@@ -144,7 +144,7 @@ struct Sweep<32> {
 
   // ubuf: LDS, 4 row buffers of NB doubles ([lane row][tj][j]); lk = NB * (lane row of this lane)
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double u1, double pinv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double u1, double pinv, int npiv) {
     constexpr int tK = K / 16, jK = K % 16, rK = (K % 16) / 4, kK = K % 4, o = 1 - tK;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
@@ -196,11 +196,15 @@ struct Sweep<32> {
 #undef YR
     // row rule: row K <- broadcast row; (K, K) <- 1/d
     row_rule2<RowMask<kK>::lo, RowMask<kK>::hi>(a[tK][0][rK], a[tK][1][rK], w[0], w[1]);
-    if constexpr (more) step<K + 1>(a, ubuf, lk, j, bad, nu0, nu1, pn);
+    if constexpr (more) {
+      if (K + 1 < npiv) step<K + 1>(a, ubuf, lk, j, bad, nu0, nu1, pn, npiv);
+    }
   }
 
   // a <- a^-1 (every pivot negative).  ubuf: 4 NB doubles of LDS nobody else touches during the sweep (one row buffer per lane row).
-  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad) {
+  // npiv < NB: rows / columns >= npiv are an identity padding (diagonal -1, zero elsewhere) -- they are not pivoted and their
+  // diagonal comes out as 0 instead of -1, which no product of a padded matrix ever sees.
+  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad, int npiv = NB) {
     const int lk = NB * k;
     ubuf[lk + j] = a[0][0][0];
     ubuf[lk + 16 + j] = a[0][1][0];
@@ -208,7 +212,7 @@ struct Sweep<32> {
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
     ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j], u1 = ubuf[16 + j];
-    step<0>(a, ubuf, lk, j, b, u0, u1, fast_rcp(d0));
+    step<0>(a, ubuf, lk, j, b, u0, u1, fast_rcp(d0), npiv);
     diag_plus_one(a[0][0][0], a[0][0][1], a[0][0][2], a[0][0][3]);
     diag_plus_one(a[1][1][0], a[1][1][1], a[1][1][2], a[1][1][3]);
     bad |= b;
@@ -224,7 +228,7 @@ struct Sweep<16> {
   typedef double Mat[1][1][4];
 
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double pinv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double pinv, int npiv) {
     constexpr int jK = K, rK = K / 4, kK = K % 4;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
@@ -250,17 +254,19 @@ struct Sweep<16> {
     }
 #undef PI
     row_rule1<RowMask<kK>::lo, RowMask<kK>::hi>(a[0][0][rK], w);
-    if constexpr (more) step<K + 1>(a, ubuf, lk, j, bad, nu0, pn);
+    if constexpr (more) {
+      if (K + 1 < npiv) step<K + 1>(a, ubuf, lk, j, bad, nu0, pn, npiv);
+    }
   }
 
-  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad) {
+  static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad, int npiv = NB) {
     const int lk = NB * k;
     ubuf[lk + j] = a[0][0][0];
     int b = 0;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
     ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j];
-    step<0>(a, ubuf, lk, j, b, u0, fast_rcp(d0));
+    step<0>(a, ubuf, lk, j, b, u0, fast_rcp(d0), npiv);
     diag_plus_one(a[0][0][0], a[0][0][1], a[0][0][2], a[0][0][3]);
     bad |= b;
   }
