@@ -15,8 +15,12 @@ hipError_t launch_small_fused(const Geo& G, const double* Kst, const double* Brh
   const int nipc = G.ncode / 3;
   if (G.b <= 48 && nw_req != 2 && nw_req != 4) {  // one wave per macro cell, matrices in registers (small_wave.h)
     const int nt = (G.b + 15) / 16;
-#define HOMMX_SW(NT_, BS_, NI_) \
-  hipLaunchKernelGGL((k_small_wave<NT_, BS_, NI_>), dim3((unsigned)nc), dim3(64), 0, st, G, Kst, Brhs, C0, out, info, nc)
+    const bool aug = G.b + G.t <= 16 * nt;  // the load rows ride in the padding columns of the arrow
+#define HOMMX_SW(NT_, BS_, NI_)                                                                                                  \
+  do {                                                                                                                           \
+    if (aug) hipLaunchKernelGGL((k_small_wave<NT_, BS_, NI_, true>), dim3((unsigned)nc), dim3(64), 0, st, G, Kst, Brhs, C0, out, info, nc); \
+    else hipLaunchKernelGGL((k_small_wave<NT_, BS_, NI_, false>), dim3((unsigned)nc), dim3(64), 0, st, G, Kst, Brhs, C0, out, info, nc);    \
+  } while (0)
 #define HOMMX_SWK(NT_)                                \
   do {                                                \
     if (G.bs == 1 && nipc == 3) HOMMX_SW(NT_, 1, 3);  \
