@@ -130,98 +130,6 @@ __device__ __forceinline__ void element_matrix_ct(const double* c, double* Cv) {
   }
 }
 
-// One thread per (cell, node): gather the (d+1) * n_sub incident elements into the node's stencil rows.
-template <int D, int KIND>
-__global__ __launch_bounds__(128) void k_assemble(Geo G, const double* __restrict__ coef,
-                                                  const double* __restrict__ Mmat, double* __restrict__ Kst,
-                                                  double* __restrict__ Brhs, long long ncells) {
-  constexpr bool EL = KIND >= HOMMX_KIND_ELASTICITY_ISO;
-  constexpr int BSV = EL ? D : 1, T = EL ? D * (D + 1) / 2 : D, NV = D + 1, NSUB = (D == 2) ? 2 : 6;
-  constexpr int NCOMP = KIND == HOMMX_KIND_POISSON_SCALAR ? 1
-                        : KIND == HOMMX_KIND_POISSON_MATRIX ? D * (D + 1) / 2
-                        : KIND == HOMMX_KIND_ELASTICITY_ISO ? 2
-                                                            : T * (T + 1) / 2;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncells * G.nn) return;
-  const long long cell = idx / G.nn;
-  const int node = (int)(idx % G.nn);
-  const int n = G.n;
-  int pc[3] = {node % n, (node / n) % n, D == 3 ? node / (n * n) : 0};
-  double M[D][D];
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) M[i][j] = Mmat ? Mmat[cell * D * D + i * D + j] : (i == j ? 1.0 : 0.0);
-  double vol = 1.0;
-#pragma unroll
-  for (int k = 0; k < D; ++k) vol /= n;
-  vol /= (D == 2 ? 2.0 : 6.0);
-  const double* ccell = coef + cell * (long long)G.n_el * NCOMP;
-  double* Kc = Kst + cell * (long long)G.ncode * BSV * BSV * G.nn;
-  double* Bc = Brhs + cell * (long long)T * BSV * G.nn;
-  for (int s = 0; s < NSUB; ++s) {
-    for (int a = 0; a < NV; ++a) {
-      // the cell whose sub-element s has its local vertex a at this node
-      int cc[3] = {0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        int v = pc[k] - G.voff[s][a][k];
-        cc[k] = v < 0 ? v + n : v;
-      }
-      const long long e = (long long)NSUB * (cc[0] + n * (cc[1] + (long long)n * cc[2])) + s;
-      double cval[NCOMP];
-#pragma unroll
-      for (int q = 0; q < NCOMP; ++q) cval[q] = ccell[e * NCOMP + q];
-      double Cv[T * T];
-      element_matrix_ct<D, KIND, T>(cval, Cv);
-      double gt[NV][D];  // g~_b = M (n grad_b)
-#pragma unroll
-      for (int b = 0; b < NV; ++b)
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          double acc = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; ++k) acc += M[i][k] * G.grad[s][b][k];
-          gt[b][i] = acc * n;
-        }
-      int code[NV];
-#pragma unroll
-      for (int b = 0; b < NV; ++b) {
-        int cd = 0, p3 = 1;
-#pragma unroll
-        for (int k = 0; k < D; ++k, p3 *= 3) cd += (G.voff[s][b][k] - G.voff[s][a][k] + 1) * p3;
-        code[b] = cd;
-      }
-#pragma unroll
-      for (int al = 0; al < BSV; ++al) {
-        double w[T], y[T];
-        strain_weights_ct<D, BSV, T>(gt[a], al, w);
-#pragma unroll
-        for (int m = 0; m < T; ++m) {
-          double acc = 0.0;
-#pragma unroll
-          for (int q = 0; q < T; ++q) acc += Cv[m * T + q] * w[q];
-          y[m] = vol * acc;
-        }
-#pragma unroll
-        for (int m = 0; m < T; ++m) Bc[((long long)m * BSV + al) * G.nn + node] -= y[m];
-#pragma unroll
-        for (int b = 0; b < NV; ++b) {
-#pragma unroll
-          for (int be = 0; be < BSV; ++be) {
-            double wb[T];
-            strain_weights_ct<D, BSV, T>(gt[b], be, wb);
-            double acc = 0.0;
-#pragma unroll
-            for (int m = 0; m < T; ++m) acc += y[m] * wb[m];
-            Kc[(((long long)code[b] * BSV + al) * BSV + be) * G.nn + node] += acc;
-          }
-        }
-      }
-    }
-  }
-}
-
 // Corner offsets of the sub-elements as compile-time constants (the same tables fill_tables() puts into Geo::voff): with them the
 // stencil slot `code` of every (sub-element, vertex, vertex) triple is a constant and the node's stencil row can stay in registers.
 template <int D>
@@ -240,8 +148,9 @@ __host__ __device__ constexpr int code_ct(int s, int a, int b) {
 
 // K1 with the node's whole stencil row (NCODE x bs x bs) and load entries accumulated in REGISTERS and written once -- no
 // read-modify-write chains through L2, no memset of the stencil array.  Same arithmetic, same order of the 24 / 6 incident
-// (sub-element, vertex) pairs as k_assemble: bitwise the same numbers.  For bs^2 * 3^d <= 36 (scalar kinds, 2D elasticity).
-template <int D, int KIND>
+// (sub-element, vertex) pairs as k_assemble: bitwise the same numbers.  ALSPLIT == 0: one thread per node (bs^2 * 3^d <= 36:
+// scalar kinds, 2D elasticity); ALSPLIT == 1: one thread per (node, row component) -- 3D elasticity, 81 + 6 accumulators per thread.
+template <int D, int KIND, int ALSPLIT>
 __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __restrict__ coef, const double* __restrict__ Mmat,
                                                       double* __restrict__ Kst, double* __restrict__ Brhs, long long ncells) {
   constexpr bool EL = KIND >= HOMMX_KIND_ELASTICITY_ISO;
@@ -250,10 +159,13 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
                         : KIND == HOMMX_KIND_POISSON_MATRIX ? D * (D + 1) / 2
                         : KIND == HOMMX_KIND_ELASTICITY_ISO ? 2
                                                             : T * (T + 1) / 2;
+  constexpr int NAL = ALSPLIT ? 1 : BSV;  // row components per thread
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncells * G.nn) return;
-  const long long cell = idx / G.nn;
-  const int node = (int)(idx % G.nn);
+  const long long nodes = ALSPLIT ? idx / BSV : idx;
+  const int al0 = ALSPLIT ? (int)(idx % BSV) : 0;
+  if (nodes >= ncells * G.nn) return;
+  const long long cell = nodes / G.nn;
+  const int node = (int)(nodes % G.nn);
   const int n = G.n;
   int pc[3] = {node % n, (node / n) % n, D == 3 ? node / (n * n) : 0};
   double M[D][D];
@@ -266,11 +178,11 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
   for (int k = 0; k < D; ++k) vol /= n;
   vol /= (D == 2 ? 2.0 : 6.0);
   const double* ccell = coef + cell * (long long)G.n_el * NCOMP;
-  double Kacc[NCODE * BSV * BSV], Bacc[T * BSV];
+  double Kacc[NCODE * NAL * BSV], Bacc[T * NAL];
 #pragma unroll
-  for (int i = 0; i < NCODE * BSV * BSV; ++i) Kacc[i] = 0.0;
+  for (int i = 0; i < NCODE * NAL * BSV; ++i) Kacc[i] = 0.0;
 #pragma unroll
-  for (int i = 0; i < T * BSV; ++i) Bacc[i] = 0.0;
+  for (int i = 0; i < T * NAL; ++i) Bacc[i] = 0.0;
 #pragma unroll
   for (int s = 0; s < NSUB; ++s) {
 #pragma unroll
@@ -298,7 +210,8 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
           gt[b][i] = acc * n;
         }
 #pragma unroll
-      for (int al = 0; al < BSV; ++al) {
+      for (int ai = 0; ai < NAL; ++ai) {
+        const int al = ALSPLIT ? al0 : ai;
         double w[T], y[T];
         strain_weights_ct<D, BSV, T>(gt[a], al, w);
 #pragma unroll
@@ -309,11 +222,9 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
           y[m] = vol * acc;
         }
 #pragma unroll
-        for (int m = 0; m < T; ++m) Bacc[m * BSV + al] -= y[m];
+        for (int m = 0; m < T; ++m) Bacc[m * NAL + ai] -= y[m];
 #pragma unroll
         for (int b = 0; b < NV; ++b) {
-          constexpr int dummy = 0;
-          (void)dummy;
 #pragma unroll
           for (int be = 0; be < BSV; ++be) {
             double wb[T];
@@ -321,7 +232,7 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
             double acc = 0.0;
 #pragma unroll
             for (int m = 0; m < T; ++m) acc += y[m] * wb[m];
-            Kacc[(code_ct<D>(s, a, b) * BSV + al) * BSV + be] += acc;
+            Kacc[(code_ct<D>(s, a, b) * NAL + ai) * BSV + be] += acc;
           }
         }
       }
@@ -330,9 +241,16 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
   double* Kc = Kst + cell * (long long)NCODE * BSV * BSV * G.nn;
   double* Bc = Brhs + cell * (long long)T * BSV * G.nn;
 #pragma unroll
-  for (int i = 0; i < NCODE * BSV * BSV; ++i) Kc[(long long)i * G.nn + node] = Kacc[i];
+  for (int code = 0; code < NCODE; ++code)
 #pragma unroll
-  for (int i = 0; i < T * BSV; ++i) Bc[(long long)i * G.nn + node] = Bacc[i];
+    for (int ai = 0; ai < NAL; ++ai)
+#pragma unroll
+      for (int be = 0; be < BSV; ++be)
+        Kc[(((long long)code * BSV + (ALSPLIT ? al0 : ai)) * BSV + be) * G.nn + node] = Kacc[(code * NAL + ai) * BSV + be];
+#pragma unroll
+  for (int m = 0; m < T; ++m)
+#pragma unroll
+    for (int ai = 0; ai < NAL; ++ai) Bc[((long long)m * BSV + (ALSPLIT ? al0 : ai)) * G.nn + node] = Bacc[m * NAL + ai];
 }
 
 // C0[cell][t][t] = sum_e vol Cv_e ; one block per cell.  Compile-time (dim, kind): the t x t partial sums stay in registers.
@@ -1381,22 +1299,17 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
     const double* coef = d_coef + c0 * G.n_el * G.ncomp;
     const double* Mm = d_M ? d_M + c0 * G.dim * G.dim : nullptr;
-    // ---- K1: stencil row in registers where it fits (scalar kinds, 2D elasticity: also no memset), else read-modify-write
+    // ---- K1: the stencil row of a node (3D elasticity: of one row component of a node) in registers, written once, no memset
     {
-      dim3 ag(nblk(nc * G.nn, 128)), ab(128);
-#define HOMMX_ASMR(D_, K_) hipLaunchKernelGGL((k_assemble_reg<D_, K_>), ag, ab, 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc)
-#define HOMMX_ASM(D_, K_) hipLaunchKernelGGL((k_assemble<D_, K_>), ag, ab, 0, st, G, coef, Mm, ws->Kst, ws->Brhs, nc)
+#define HOMMX_ASMR(D_, K_, SPLIT_)                                                                                          \
+  hipLaunchKernelGGL((k_assemble_reg<D_, K_, SPLIT_>), dim3(nblk(nc * G.nn * (SPLIT_ ? D_ : 1), 128)), dim3(128), 0, st, G, coef, Mm, \
+                     ws->Kst, ws->Brhs, nc)
       if (G.dim == 2) {
-        if (G.kind == 0) HOMMX_ASMR(2, 0); else if (G.kind == 1) HOMMX_ASMR(2, 1); else if (G.kind == 2) HOMMX_ASMR(2, 2); else HOMMX_ASMR(2, 3);
-      } else if (G.kind <= 1) {
-        if (G.kind == 0) HOMMX_ASMR(3, 0); else HOMMX_ASMR(3, 1);
+        if (G.kind == 0) HOMMX_ASMR(2, 0, 0); else if (G.kind == 1) HOMMX_ASMR(2, 1, 0); else if (G.kind == 2) HOMMX_ASMR(2, 2, 0); else HOMMX_ASMR(2, 3, 0);
       } else {
-        BTRY(hipMemsetAsync(ws->Kst, 0, 8ll * nc * G.ncode * G.bs * G.bs * G.nn, st));
-        BTRY(hipMemsetAsync(ws->Brhs, 0, 8ll * nc * G.t * G.bs * G.nn, st));
-        if (G.kind == 2) HOMMX_ASM(3, 2); else HOMMX_ASM(3, 3);
+        if (G.kind == 0) HOMMX_ASMR(3, 0, 0); else if (G.kind == 1) HOMMX_ASMR(3, 1, 0); else if (G.kind == 2) HOMMX_ASMR(3, 2, 1); else HOMMX_ASMR(3, 3, 1);
       }
 #undef HOMMX_ASMR
-#undef HOMMX_ASM
     }
     {
 #define HOMMX_C0(D_, K_) hipLaunchKernelGGL((k_c0<D_, K_>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0)

@@ -656,6 +656,9 @@ hipError_t launch_poisson2d_fused(const double* d_coef, const double* d_M, doubl
                                   int n, long long ncells, hipStream_t stream, CoefSource src) {
   if (ncells <= 0) return hipSuccess;
   dim3 grid((unsigned)ncells), block(64);
+#ifndef HOMMX_DEV_LDS_PAD
+#define HOMMX_DEV_LDS_PAD 0  // dev builds: dynamic LDS bytes per workgroup, to pin the occupancy for latency experiments
+#endif
 #ifdef HOMMX_FUSED_DEBUG
   extern double* g_fused_dbg;
   if (n <= 16)
@@ -664,9 +667,9 @@ hipError_t launch_poisson2d_fused(const double* d_coef, const double* d_M, doubl
     hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src, g_fused_dbg);
 #else
   if (n <= 16)
-    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src);
+    hipLaunchKernelGGL(k_poisson2d_fused<16>, grid, block, HOMMX_DEV_LDS_PAD, stream, d_coef, d_M, d_out, d_info, n, ncells, src);
   else
-    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, 0, stream, d_coef, d_M, d_out, d_info, n, ncells, src);
+    hipLaunchKernelGGL(k_poisson2d_fused<32>, grid, block, HOMMX_DEV_LDS_PAD, stream, d_coef, d_M, d_out, d_info, n, ncells, src);
 #endif
   return hipGetLastError();
 }

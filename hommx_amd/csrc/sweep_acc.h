@@ -112,14 +112,18 @@ __device__ __forceinline__ unsigned lds_offset(T* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)p;
 }
 
-// "not a usable pivot" of T = -S: d must be negative, normal and finite (tested on the scalar unit, d comes from v_readlane)
-__device__ __forceinline__ int bad_neg_pivot_hi(int hi) { return (unsigned)((hi ^ (int)0x80000000) - 1) >= 0x7fefffffu; }
-__device__ __forceinline__ double readlane_neg_pivot(double v, int lane, int& bad) {
+// "not a usable pivot" of T = -S: d must be negative, normal and finite, i.e. its high word in [0x80100000, 0xffefffff], i.e.
+// hi + 0x00100000 >= 0x80200000 without wrapping.  d comes from v_readlane; the running minimum of hi + 0x00100000 over the pivots of
+// a sweep stays on the scalar unit (2 SALU per pivot: left to itself the compiler builds a v_min3_u32 chain on the vector unit).
+__device__ __forceinline__ double readlane_neg_pivot(double v, int lane, unsigned& mn) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  bad |= bad_neg_pivot_hi(hi);
+  unsigned t;
+  asm("s_add_u32 %0, %1, 0x100000" : "=s"(t) : "s"(hi) : "scc");
+  asm("s_min_u32 %0, %0, %1" : "+s"(mn) : "s"(t) : "scc");
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int bad_pivot_min(unsigned mn) { return mn < 0x80200000u; }
 
 #define HOMMX_BC " row_newbcast:%[jk] row_mask:0xf bank_mask:0xf\n\t"
 // y += bcast(x) * wo ; x += bcast(x) * wk   (x = register of the pivot's column tile, y = the other column tile)
@@ -144,7 +148,7 @@ struct Sweep<32> {
 
   // ubuf: LDS, 4 row buffers of NB doubles ([lane row][tj][j]); lk = NB * (lane row of this lane)
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double u1, double pinv, int npiv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, unsigned& bad, double u0, double u1, double pinv, int npiv) {
     constexpr int tK = K / 16, jK = K % 16, rK = (K % 16) / 4, kK = K % 4, o = 1 - tK;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
@@ -208,14 +212,14 @@ struct Sweep<32> {
     const int lk = NB * k;
     ubuf[lk + j] = a[0][0][0];
     ubuf[lk + 16 + j] = a[0][1][0];
-    int b = 0;
+    unsigned b = 0xffffffffu;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
     ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j], u1 = ubuf[16 + j];
     step<0>(a, ubuf, lk, j, b, u0, u1, fast_rcp(d0), npiv);
     diag_plus_one(a[0][0][0], a[0][0][1], a[0][0][2], a[0][0][3]);
     diag_plus_one(a[1][1][0], a[1][1][1], a[1][1][2], a[1][1][3]);
-    bad |= b;
+    bad |= bad_pivot_min(b);
   }
 };
 
@@ -228,7 +232,7 @@ struct Sweep<16> {
   typedef double Mat[1][1][4];
 
   template <int K>
-  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, int& bad, double u0, double pinv, int npiv) {
+  static __device__ __forceinline__ void step(Mat& a, double* ubuf, int lk, int j, unsigned& bad, double u0, double pinv, int npiv) {
     constexpr int jK = K, rK = K / 4, kK = K % 4;
     constexpr bool more = K + 1 < NB;
     constexpr int K1 = more ? K + 1 : K;
@@ -262,13 +266,13 @@ struct Sweep<16> {
   static __device__ __forceinline__ void run(Mat& a, double* ubuf, int j, int k, int& bad, int npiv = NB) {
     const int lk = NB * k;
     ubuf[lk + j] = a[0][0][0];
-    int b = 0;
+    unsigned b = 0xffffffffu;
     const double d0 = readlane_neg_pivot(a[0][0][0], 0, b);
     ubuf[0] = d0 - 1.0;
     const double u0 = ubuf[j];
     step<0>(a, ubuf, lk, j, b, u0, fast_rcp(d0), npiv);
     diag_plus_one(a[0][0][0], a[0][0][1], a[0][0][2], a[0][0][3]);
-    bad |= b;
+    bad |= bad_pivot_min(b);
   }
 };
 

@@ -13,6 +13,10 @@ cases = [(2, 10, "elasticity", 0, 8192), (3, 6, "poisson", 0, 8192), (2, 16, "po
          (3, 12, "elasticity", 0, 1024), (3, 16, "elasticity", 0, 1024)]
 if only_small:
     cases = cases[:4]
+for a in sys.argv[1:]:  # --case=dim,n,kind,cells
+    if a.startswith("--case="):
+        d_, n_, k_, c_ = a[7:].split(",")
+        cases = [(int(d_), int(n_), k_, 1, int(c_))]
 for dim, n, kind, flags, nc in cases:
     p = MicroCellPlan(dim, n, kind, flags=flags)
     shape = (nc, p.n_el) + ((p.n_comp,) if p.n_comp > 1 else ())
