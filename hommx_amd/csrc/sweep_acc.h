@@ -113,14 +113,14 @@ __device__ __forceinline__ unsigned lds_offset(T* p) {
 }
 
 // "not a usable pivot" of T = -S: d must be negative, normal and finite, i.e. its high word in [0x80100000, 0xffefffff], i.e.
-// hi + 0x00100000 >= 0x80200000 without wrapping.  d comes from v_readlane; the running minimum of hi + 0x00100000 over the pivots of
-// a sweep stays on the scalar unit (2 SALU per pivot: left to itself the compiler builds a v_min3_u32 chain on the vector unit).
+// hi + 0x00100000 >= 0x80200000 without wrapping.  d comes from v_readlane; the sweep keeps the running minimum of hi + 0x00100000.
+// (The compiler folds the 32 minima into a v_min3_u32 chain AFTER the sweep; forcing them onto the scalar unit with inline asm puts
+// 2 SALU per pivot into the dependent chain behind v_readlane and costs 1 % of the kernel: measured, rejected.)
 __device__ __forceinline__ double readlane_neg_pivot(double v, int lane, unsigned& mn) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  unsigned t;
-  asm("s_add_u32 %0, %1, 0x100000" : "=s"(t) : "s"(hi) : "scc");
-  asm("s_min_u32 %0, %0, %1" : "+s"(mn) : "s"(t) : "scc");
+  const unsigned t = (unsigned)hi + 0x100000u;
+  mn = t < mn ? t : mn;
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int bad_pivot_min(unsigned mn) { return mn < 0x80200000u; }
