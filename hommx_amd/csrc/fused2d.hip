@@ -310,7 +310,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
     // (1) N = T^-1
     {
       int badj = 0;
+#ifdef HOMMX_FUSED_SWEEP32
       accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
+#else
+      if constexpr (NB == 32) accl::block_inverse32(a, L.ubuf, j, k, badj);
+      else accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
+#endif
       if (badj && !bad) { bad = 1; badstep = jr + 1; }
     }
 #ifdef HOMMX_FUSED_DEBUG

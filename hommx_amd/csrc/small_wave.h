@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
     if constexpr (NT == 1) {
       accl::Sweep<16>::run(T, ubuf, lj, lk, bad, b);
     } else if constexpr (NT == 2) {
-      accl::Sweep<32>::run(T, ubuf, lj, lk, bad, b);
+      accl::block_inverse32(T, ubuf, lj, lk, bad, b);
     } else {
       // T = [[TA, U], [U^T, TC]], TA 32 x 32, TC 16 x 16:  Ai = TA^-1,  X = U^T Ai,  Sc = TC - X U,  N22 = Sc^-1,  N21 = -N22 X,
       // N12 = N21^T,  N11 = Ai - X^T N21.   Held: nx = -X (16 x 32, tiles nx[tj]),  nxt = -X^T (32 x 16, tiles nxt[ti]).
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
 #pragma unroll
           for (int tj = 0; tj < 2; ++tj) a[ti][tj][r] = T[ti][tj][r];
         }
-      accl::Sweep<32>::run(a, ubuf, lj, lk, bad, 32);
+      accl::block_inverse32(a, ubuf, lj, lk, bad, 32);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         d4 cx = d4{0.0, 0.0, 0.0, 0.0}, ct = d4{0.0, 0.0, 0.0, 0.0};
