@@ -257,7 +257,11 @@ struct Sweep<16> {
                    : [wk] "v"(w), [jk] "n"(jK));
     }
 #undef PI
+#ifdef HOMMX_ROW_RULE_EXEC
     row_rule1<RowMask<kK>::lo, RowMask<kK>::hi>(a[0][0][rK], w);
+#else
+    a[0][0][rK] = (lk == NB * kK) ? w : a[0][0][rK];  // two v_cndmask_b32 on a loop-invariant lane-row mask: cheaper than 3 SALU + 1 move
+#endif
     if constexpr (more) {
       if (K + 1 < npiv) step<K + 1>(a, ubuf, lk, j, bad, nu0, pn, npiv);
     }
