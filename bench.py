@@ -45,6 +45,18 @@ def flop_model(n: int, b: int | None = None) -> float:
     return (6.0 * (n - 1) + 2.0) * b**3
 
 
+def flops_executed_fused2d(n: int) -> float:
+    """FMAs x 2 the fused 2D kernel issues per solve on its padded block size NB (csrc/fused2d.hip, sweep_acc.h): per eliminated node row
+    the inverse (NB = 32: two 16-sweeps + 16 MFMAs of the 2 x 2 block inverse; NB = 16: one 16-sweep), V'^T = N W^T (all tiles) and
+    S_last += V' W^T (tiles on and below the diagonal); + the inverse of the last block.  The sparse coupling and load-row work
+    (vector unit, about 8 % more) is not counted."""
+    if n > 16:
+        inv, v, sl = 2 * 16 * 256 + 16 * 1024, 32 * 1024, 24 * 1024
+    else:
+        inv, v, sl = 16 * 256, 4 * 1024, 4 * 1024
+    return 2.0 * ((n - 1) * (inv + v + sl) + inv)
+
+
 def flops_ref(dim: int, n: int, bs: int, nrhs: int) -> dict:
     """F_ref of SURVEY 8(d): sparse-Cholesky flops under a fill-reducing ordering (tools/fref.py); the 3D figure takes a
     minute of symbolic analysis, so it is read from the committed profiles/fref.json when it is there."""
@@ -296,7 +308,11 @@ def main():
                 "kernel": "k_poisson2d_fused<32>" if n > 16 else "k_poisson2d_fused<16>",
                 "kernel_ms": kern_ms,
                 "flops_per_solve": flop_model(n),
-                "flop_model": "dense block-cyclic elimination, (6 (n-1) + 2) n^3: what the kernel executes (DESIGN.md section 2)",
+                "flop_model": "algorithmic: dense block-cyclic elimination without symmetry savings, (6 (n-1) + 2) n^3 (DESIGN.md section 2; "
+                "the model of every round, so `frac` compares across rounds)",
+                # what the kernel really issues: lower tiles of S_last, 2 x 2 block inverse with transposed tiles
+                "flops_executed_per_solve": flops_executed_fused2d(n),
+                "frac_executed": flops_executed_fused2d(n) * nc / (kern_ms * 1e-3) / FP64_PEAK_DATASHEET,
                 # the same rate priced with the flops a sparse Cholesky under a fill-reducing ordering needs
                 "flops_ref_per_solve": fr["F_ref"],
                 "flops_ref_ordering": fr["ordering"],

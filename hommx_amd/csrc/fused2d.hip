@@ -62,6 +62,7 @@ template <int NB>
 struct alignas(16) Lds {
   double mat[(NB + 1) * MATP];
   double ubuf[4 * NB];  // sweep: raw pivot rows, one buffer per lane row: [k][tj][j]
+  double tsc[16 * 17];  // tile transposes of the 2 x 2 block inverse
   double rrow[2][NB];   // R of the current block, row layout: [m][(i & 3) * KK + (i >> 2)]
   double vrow[2][NB];   // Vr' = R N, row layout
   double vnat[2][NB];   // Vr', natural order
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #ifdef HOMMX_FUSED_SWEEP32
       accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
 #else
-      if constexpr (NB == 32) accl::block_inverse32(a, L.ubuf, j, k, badj);
+      if constexpr (NB == 32) accl::block_inverse32(a, L.ubuf, L.tsc, j, k, badj);
       else accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
 #endif
       if (badj && !bad) { bad = 1; badstep = jr + 1; }

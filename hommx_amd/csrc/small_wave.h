@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
   __shared__ double pad[BP * BP];
   __shared__ double SLm[BP * BP];  // S_last (AUG: bordered with R_last^T and -G): touched once per step, upper tiles only
   __shared__ double ubuf[4 * 32];
+  __shared__ double tsc[NT >= 2 ? 16 * 17 : 1];  // tile transposes of the 32 x 32 block inverse
 
   const long long cell = blockIdx.x;
   if (cell >= ncells) return;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
     if constexpr (NT == 1) {
       accl::Sweep<16>::run(T, ubuf, lj, lk, bad, b);
     } else if constexpr (NT == 2) {
-      accl::block_inverse32(T, ubuf, lj, lk, bad, b);
+      accl::block_inverse32(T, ubuf, tsc, lj, lk, bad, b);
     } else {
       // T = [[TA, U], [U^T, TC]], TA 32 x 32, TC 16 x 16:  Ai = TA^-1,  X = U^T Ai,  Sc = TC - X U,  N22 = Sc^-1,  N21 = -N22 X,
       // N12 = N21^T,  N11 = Ai - X^T N21.   Held: nx = -X (16 x 32, tiles nx[tj]),  nxt = -X^T (32 x 16, tiles nxt[ti]).
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
 #pragma unroll
           for (int tj = 0; tj < 2; ++tj) a[ti][tj][r] = T[ti][tj][r];
         }
-      accl::block_inverse32(a, ubuf, lj, lk, bad, 32);
+      accl::block_inverse32(a, ubuf, tsc, lj, lk, bad, 32);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         d4 cx = d4{0.0, 0.0, 0.0, 0.0}, ct = d4{0.0, 0.0, 0.0, 0.0};

@@ -290,19 +290,31 @@ struct Sweep<16> {
 // fp64 pipe time as the 32-sweep (24 MFMAs = 384 FMA slots replace 32 x 16 - 2 x 16 x 4 = 384 DPP FMAs), but 2 x 16 x 12 fewer
 // bookkeeping slots and half the dependent pivot chain: a wave issues one fp64 VALU op per ~8 cycles, an MFMA carries 16 of them.
 typedef double v4d __attribute__((ext_vector_type(4)));
-// npiv (> 16) < 32: rows / columns >= npiv are an identity padding, see Sweep<32>::run.
-__device__ __forceinline__ void block_inverse32(double (&a)[2][2][4], double* ubuf, int j, int k, int& bad, int npiv = 32) {
+// transpose of a 16 x 16 tile held in the acc layout, through 16 x 17 doubles of LDS (pitch 17: both passes conflict-free); one wave
+__device__ __forceinline__ v4d transpose_tile(v4d x, double* tsc, int j, int k) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tsc[(4 * r + k) * 17 + j] = x[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  v4d y;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = tsc[j * 17 + 4 * r + k];
+  __builtin_amdgcn_wave_barrier();
+  return y;
+}
+// tsc: 16 x 17 doubles of LDS scratch.  npiv (> 16) < 32: rows / columns >= npiv are an identity padding, see Sweep<32>::run.
+// Ai U is formed on the matrix cores and its transpose U^T Ai taken through LDS; likewise N12 = N21^T: 16 MFMAs, not 24.
+__device__ __forceinline__ void block_inverse32(double (&a)[2][2][4], double* ubuf, double* tsc, int j, int k, int& bad, int npiv = 32) {
   auto mm = [](double x, double y, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); };
   double t00[1][1][4], sc[1][1][4], nu[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { t00[0][0][r] = a[0][0][r]; nu[r] = -a[0][1][r]; }
   Sweep<16>::run(t00, ubuf, j, k, bad);
-  v4d nx = v4d{0.0, 0.0, 0.0, 0.0}, nxt = v4d{0.0, 0.0, 0.0, 0.0};
+  v4d nxt = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    nx = mm(nu[q], t00[0][0][q], nx);    // -X[i][j]   = sum_k (-U[k][i]) Ai[k][j]
-    nxt = mm(t00[0][0][q], nu[q], nxt);  // -X^T[i][j] = sum_k Ai[k][i] (-U[k][j])
-  }
+  for (int q = 0; q < 4; ++q) nxt = mm(t00[0][0][q], nu[q], nxt);  // -X^T[i][j] = sum_k Ai[k][i] (-U[k][j])
+  const v4d nx = transpose_tile(nxt, tsc, j, k);                   // -X = -U^T Ai
   {
     v4d c = v4d{a[1][1][0], a[1][1][1], a[1][1][2], a[1][1][3]};
 #pragma unroll
@@ -311,15 +323,13 @@ __device__ __forceinline__ void block_inverse32(double (&a)[2][2][4], double* ub
     for (int r = 0; r < 4; ++r) sc[0][0][r] = c[r];
   }
   Sweep<16>::run(sc, ubuf, j, k, bad, npiv - 16);
-  v4d n21 = v4d{0.0, 0.0, 0.0, 0.0}, n12 = v4d{0.0, 0.0, 0.0, 0.0};
+  v4d n21 = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    n21 = mm(sc[0][0][q], nx[q], n21);  // N21 = N22 (-X)
-    n12 = mm(nx[q], sc[0][0][q], n12);  // N12 = (-X)^T N22
-  }
+  for (int q = 0; q < 4; ++q) n21 = mm(sc[0][0][q], nx[q], n21);  // N21 = N22 (-X)
   v4d n11 = v4d{t00[0][0][0], t00[0][0][1], t00[0][0][2], t00[0][0][3]};
 #pragma unroll
   for (int q = 0; q < 4; ++q) n11 = mm(nx[q], n21[q], n11);  // N11 = Ai + (-X)^T N21
+  const v4d n12 = transpose_tile(n21, tsc, j, k);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     a[0][0][r] = n11[r];
