@@ -857,7 +857,7 @@ struct BlockedWorkspace {
   bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
   bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
   bool small_fused = true;     // HOMMX_NO_SMALL_FUSED switches the LDS-resident kernel for b <= 64 off (A/B runs)
-  int small_waves = 0;         // HOMMX_SMALL_WAVES: waves per macro cell of that kernel (1 / 2 / 4; 0 = default)
+  int small_waves = 0;         // HOMMX_SMALL_WAVES: 2 / 4 = the LDS kernel with that many waves per macro cell; 0 = default routes
   long long chunk = 0;
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
   double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
@@ -1321,11 +1321,10 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
 #undef HOMMX_C0
     }
     if (G.b <= 64 && !d_corr && ws->small_fused) {
-      // small plane blocks: the whole elimination in ONE launch, matrices in LDS (small_fused.h)
+      // small plane blocks: the whole elimination in ONE launch -- b <= 48: one wave per macro cell, matrices in registers
+      // (small_wave.h); 48 < b <= 64, or HOMMX_SMALL_WAVES = 2 | 4: that many waves per cell, matrices in LDS (small_fused.h)
       double* o = d_out + c0 * G.t * G.t;
       int32_t* inf = d_info ? d_info + c0 : nullptr;
-      // waves per macro cell (HOMMX_SMALL_WAVES, dev knob; 0 = default: 2 for b <= 48, 4 for b = 64, profiles/r02_kinds.txt): few
-      // waves per cell and many cells per CU beat one wave per tile -- the elimination is a chain of short phases
       BTRY(launch_small_fused(G, ws->Kst, ws->Brhs, ws->C0, o, inf, nc, ws->small_waves, st));
       BTRY(hipGetLastError());
       continue;

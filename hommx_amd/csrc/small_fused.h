@@ -1,11 +1,11 @@
 // small_fused.h -- LDS-resident fused elimination for SMALL plane blocks (b = bs * n^(d-1) <= 64), compiled in small.hip.
 //
-// The blocked family spends ~2,700 launches and six HBM-resident b x b matrices per chunk; for the sizes of the reference's own
-// tests -- 2D elasticity on 10 x 10 micro cells (b = 20: test_integration_linear_elasticity.py:62-171), 3D Poisson on 6^3
-// (b = 36: test_integration_poisson.py:243-294), matrix-valued 2D Poisson -- the matrices fit in LDS.  After K1 (k_assemble,
-// k_c0: the stencil of every node in HBM, read once) ONE workgroup per macro cell -- one wave per 16 x 16 tile of the padded
-// block, BP = 32 / 48 / 64, i.e. 4 / 9 / 16 waves -- runs the whole block-cyclic elimination (same recurrences and signs as
-// blocked_solve) with S, W^T and V^T in LDS and S_last in MFMA accumulators (one tile per wave):
+// Default route for 48 < b <= 64 only (a 64 x 64 block does not fit one wave's registers); blocks b <= 48 take the one-wave-per-cell
+// register kernel of small_wave.h and come here only with HOMMX_SMALL_WAVES=2|4 (A/B tests).
+//
+// After K1 (k_assemble_reg, k_c0: the stencil of every node in HBM, read once) ONE workgroup of NW waves per macro cell -- tiles of the
+// padded block, BP = 32 / 48 / 64, dealt round-robin to the waves -- runs the whole block-cyclic elimination (same recurrences and signs
+// as blocked_solve) with S, W^T and V^T in LDS and S_last in MFMA accumulators:
 //
 //     Sinv = S^-1          32 x 32 (and 16 x 16) exchange sweeps in the MFMA accumulator layout by ONE wave (sweep_acc.h: DPP
 //                          column broadcasts, no barrier per pivot); 48 / 64: 2 x 2 block inverse, Schur products on the matrix cores
