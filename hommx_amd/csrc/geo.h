@@ -30,4 +30,8 @@ __device__ __forceinline__ int plane_neighbour(const Geo& G, int q, int ipc) {
 hipError_t launch_small_fused(const Geo& G, const double* Kst, const double* Brhs, const double* C0, double* out, int32_t* info,
                               long long ncells, int nw, hipStream_t stream);
 
+// small_wave.hip: register-resident elimination for plane blocks b <= 48, one wavefront per macro cell (small_wave.h)
+hipError_t launch_small_wave(const Geo& G, const double* Kst, const double* Brhs, const double* C0, double* out, int32_t* info,
+                             long long ncells, hipStream_t stream);
+
 }  // namespace hommx

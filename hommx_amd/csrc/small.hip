@@ -1,11 +1,10 @@
 // small.hip -- translation unit of the LDS-resident small-block kernel (small_fused.h) and its dispatch over
-// (padded block size, components per node, in-plane stencil size, waves per macro cell).
+// (padded block size, components per node, in-plane stencil size, waves per macro cell); blocks b <= 48 go on to small_wave.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "geo.h"
 #include "small_fused.h"
-#include "small_wave.h"
 
 namespace hommx {
 
@@ -13,26 +12,7 @@ hipError_t launch_small_fused(const Geo& G, const double* Kst, const double* Brh
                               long long nc, int nw_req, hipStream_t st) {
   if (nc <= 0) return hipSuccess;
   const int nipc = G.ncode / 3;
-  if (G.b <= 48 && nw_req != 2 && nw_req != 4) {  // one wave per macro cell, matrices in registers (small_wave.h)
-    const int nt = (G.b + 15) / 16;
-    const bool aug = G.b + G.t <= 16 * nt;  // the load rows ride in the padding columns of the arrow
-#define HOMMX_SW(NT_, BS_, NI_)                                                                                                  \
-  do {                                                                                                                           \
-    if (aug) hipLaunchKernelGGL((k_small_wave<NT_, BS_, NI_, true>), dim3((unsigned)nc), dim3(64), 0, st, G, Kst, Brhs, C0, out, info, nc); \
-    else hipLaunchKernelGGL((k_small_wave<NT_, BS_, NI_, false>), dim3((unsigned)nc), dim3(64), 0, st, G, Kst, Brhs, C0, out, info, nc);    \
-  } while (0)
-#define HOMMX_SWK(NT_)                                \
-  do {                                                \
-    if (G.bs == 1 && nipc == 3) HOMMX_SW(NT_, 1, 3);  \
-    else if (G.bs == 2) HOMMX_SW(NT_, 2, 3);          \
-    else if (G.bs == 1) HOMMX_SW(NT_, 1, 9);          \
-    else HOMMX_SW(NT_, 3, 9);                         \
-  } while (0)
-    if (nt == 1) HOMMX_SWK(1); else if (nt == 2) HOMMX_SWK(2); else HOMMX_SWK(3);
-#undef HOMMX_SWK
-#undef HOMMX_SW
-    return hipGetLastError();
-  }
+  if (G.b <= 48 && nw_req != 2 && nw_req != 4) return launch_small_wave(G, Kst, Brhs, C0, out, info, nc, st);  // small_wave.hip
   const int bp = G.b <= 32 ? 32 : G.b <= 48 ? 48 : 64;
   const int nw = (nw_req == 2 || nw_req == 4) ? nw_req : (bp == 64 ? 4 : 2);
 #define HOMMX_SF(BP_, BS_, NI_, NW_) \
