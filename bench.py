@@ -180,8 +180,8 @@ def timed_steps(step, steps, warmup, use_dist, dist, dev, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 50 for C2, 1 for C5)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 10 for C2, 0 for C5)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 1000 for C2 -- 1.2 s of GPU time, long enough for an external utilisation sampler; 1 for C5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default: 20 for C2, 0 for C5)")
     ap.add_argument("--config", choices=("C2", "C5"), default="C2")
     ap.add_argument("--macro", type=int, default=64, help="C2: macro cells per side (64)")
     ap.add_argument("--micro", type=int, default=None, help="micro cells per side (C2: 32, C5: 16)")
@@ -195,9 +195,9 @@ def main():
     if args.micro is None:
         args.micro = 32 if args.config == "C2" else 16
     if args.steps is None:
-        args.steps = 50 if args.config == "C2" else 1
+        args.steps = 1000 if args.config == "C2" else 1
     if args.warmup is None:
-        args.warmup = 10 if args.config == "C2" else 0
+        args.warmup = 20 if args.config == "C2" else 0
     if args.cpu_worker:
         return cpu_worker(args)
 
