@@ -40,9 +40,8 @@ __device__ __forceinline__ int swz(int row, int col) {
   return row * BP + (col ^ ((row & 1) << 4));
 }
 
-// waves per SIMD the register budget has to admit: BP = 32 is LDS-bound at 5 cells per CU (28 KB each), i.e. 3 waves on some SIMDs
 template <int BP, int BSV, int NIPC, int NW>
-__global__ __launch_bounds__(NW * 64, (BP == 32 ? (NW == 2 ? 3 : 5) : 1)) void k_small_fused(Geo G, const double* __restrict__ Kst,
+__global__ __launch_bounds__(NW * 64) void k_small_fused(Geo G, const double* __restrict__ Kst,
                                                                               const double* __restrict__ Brhs,
                                                                               const double* __restrict__ C0, double* __restrict__ out,
                                                                               int32_t* __restrict__ info, long long ncells) {
@@ -59,6 +58,7 @@ __global__ __launch_bounds__(NW * 64, (BP == 32 ? (NW == 2 ? 3 : 5) : 1)) void k
   __shared__ double VT[BP * BP];      // V^T, Z = E Sinv; scratch of the block inverse
   __shared__ double RT[BP * LP], RlT[BP * LP], VrT[BP * LP];  // R^T, R_last^T, Vr^T
   __shared__ double ubuf[4 * 32];     // pivot-row buffers of the sweeps
+  __shared__ double tsc[16 * 17];     // tile transposes of the 32 x 32 block inverse
   __shared__ int badflag;
 
   const long long cell = blockIdx.x;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, (BP == 32 ? (NW == 2 ? 3 : 5) : 1)) void k
 #pragma unroll
           for (int r = 0; r < 4; ++r) a[ti][tj][r] = -M[swz<BP>(o + 16 * ti + 4 * r + lk, o + 16 * tj + lj)];
       __builtin_amdgcn_s_setprio(3);  // the rest of the workgroup waits for this wave
-      accl::Sweep<32>::run(a, ubuf, lj, lk, bad);
+      accl::block_inverse32(a, ubuf, tsc, lj, lk, bad);  // 2 x 2 blocks around two 16-sweeps (sweep_acc.h)
       __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
