@@ -15,7 +15,7 @@
 //     SLa = [[S_last, R_last^T], [., -G]]  is ONE symmetric matrix, and the four narrow products of the load rows disappear:
 //         N = T^-1 ;  nv = N A ;  SLa += nv^T A ;  A' = [0 | -P^T] + ET^T nv ;  nz = N ET ;  T' = -D + (-nz)^T ET
 //     (T = -S carried negated: the exchange sweeps of sweep_acc.h work in place and skip the pivots of the identity padding;
-//      BP = 48: 2 x 2 block inverse around a 32- and a 16-sweep, its Schur products on the matrix cores)
+//      32 x 32: accl::block_inverse32, two 16-sweeps + 16 MFMAs; BP = 48: one more 2 x 2 level around that and a 16-sweep)
 //   * k-slabs behind row b hold zeros: each product is compiled for 4 NT - 3 .. 4 NT slabs and the wave picks its variant
 //   * SLa is symmetric and lives in LDS: only its upper tiles are updated
 //
