@@ -253,22 +253,26 @@ __global__ __launch_bounds__(128) void k_assemble_reg(Geo G, const double* __res
     for (int ai = 0; ai < NAL; ++ai) Bc[((long long)m * BSV + (ALSPLIT ? al0 : ai)) * G.nn + node] = Bacc[m * NAL + ai];
 }
 
-// C0[cell][t][t] = sum_e vol Cv_e ; one block per cell.  Compile-time (dim, kind): the t x t partial sums stay in registers.
-// Fixed summation order (thread-strided partial sums, wave butterfly, four wave totals added in order): bitwise reproducible.
-template <int D, int KIND>
-__global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ coef, double* __restrict__ C0) {
+// C0[cell][t][t] = sum_e vol Cv_e.  Compile-time (dim, kind): the t x t partial sums stay in registers.  WPC waves per macro cell
+// (4: one 256-thread block per cell; 1: small meshes, four cells per block, no LDS, no barrier).  Fixed summation order (lane-strided
+// partial sums, wave butterfly, wave totals added in order): bitwise reproducible.
+template <int D, int KIND, int WPC>
+__global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ coef, double* __restrict__ C0, long long ncells) {
   constexpr bool EL = KIND >= HOMMX_KIND_ELASTICITY_ISO;
   constexpr int T = EL ? D * (D + 1) / 2 : D, TT = T * T;
   constexpr int NCOMP = KIND == HOMMX_KIND_POISSON_SCALAR ? 1
                         : KIND == HOMMX_KIND_POISSON_MATRIX ? D * (D + 1) / 2
                         : KIND == HOMMX_KIND_ELASTICITY_ISO ? 2
                                                             : T * (T + 1) / 2;
-  const long long cell = blockIdx.x;
+  constexpr int NTH = 64 * WPC;  // threads per cell
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long cell = WPC == 4 ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave;
+  if (cell >= ncells) return;  // WPC == 1: whole waves leave, nothing below synchronises across waves
   double acc[TT];
 #pragma unroll
   for (int i = 0; i < TT; ++i) acc[i] = 0.0;
   const double* ccell = coef + cell * (long long)G.n_el * NCOMP;
-  for (int e = threadIdx.x; e < G.n_el; e += 256) {
+  for (int e = WPC == 4 ? threadIdx.x : lane; e < G.n_el; e += NTH) {
     double cval[NCOMP], Cv[TT];
 #pragma unroll
     for (int q = 0; q < NCOMP; ++q) cval[q] = ccell[(long long)e * NCOMP + q];
@@ -276,20 +280,26 @@ __global__ __launch_bounds__(256) void k_c0(Geo G, const double* __restrict__ co
 #pragma unroll
     for (int i = 0; i < TT; ++i) acc[i] += Cv[i];
   }
-  __shared__ double red[4][TT];
   double vol = 1.0;
   for (int k = 0; k < D; ++k) vol /= G.n;
   vol /= (D == 2 ? 2.0 : 6.0);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < TT; ++i) {
-    double v = acc[i];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) red[wave][i] = v;
+    for (int off = 32; off >= 1; off >>= 1) acc[i] += __shfl_xor(acc[i], off, 64);
   }
-  __syncthreads();
-  if (threadIdx.x < TT) C0[cell * TT + threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * vol;
+  if constexpr (WPC == 1) {
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+      if (lane == i) C0[cell * TT + i] = acc[i] * vol;
+  } else {
+    __shared__ double red[4][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+      if (lane == 0) red[wave][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < TT) C0[cell * TT + threadIdx.x] = (((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]) * vol;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1312,7 +1322,11 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
 #undef HOMMX_ASMR
     }
     {
-#define HOMMX_C0(D_, K_) hipLaunchKernelGGL((k_c0<D_, K_>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0)
+#define HOMMX_C0(D_, K_)                                                                                                  \
+  do {                                                                                                                    \
+    if (G.n_el <= 4096) hipLaunchKernelGGL((k_c0<D_, K_, 1>), dim3(nblk(nc, 4)), dim3(256), 0, st, G, coef, ws->C0, nc);   \
+    else hipLaunchKernelGGL((k_c0<D_, K_, 4>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0, nc);                 \
+  } while (0)
       if (G.dim == 2) {
         if (G.kind == 0) HOMMX_C0(2, 0); else if (G.kind == 1) HOMMX_C0(2, 1); else if (G.kind == 2) HOMMX_C0(2, 2); else HOMMX_C0(2, 3);
       } else {
