@@ -314,8 +314,12 @@ __global__ __launch_bounds__(64, HOMMX_FUSED_WAVES_PER_SIMD) void k_poisson2d_fu
 #ifdef HOMMX_FUSED_SWEEP32
       accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
 #else
+      // the inverse is one dependent chain (pivot after pivot): let it issue ahead of the other wave of the SIMD, whose MFMA / sparse
+      // phases have slack (+2 %; priority everywhere but the MFMA block: no gain)
+      __builtin_amdgcn_s_setprio(1);
       if constexpr (NB == 32) accl::block_inverse32(a, L.ubuf, L.tsc, j, k, badj);
       else accl::Sweep<NB>::run(a, L.ubuf, j, k, badj);
+      __builtin_amdgcn_s_setprio(0);
 #endif
       if (badj && !bad) { bad = 1; badstep = jr + 1; }
     }

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
 
   // ---- T <- T^-1 for T = -S, S SPD with an identity padding behind row b ----------------------------------------------------------------------
   auto invert = [&](Mat& T, int& bad) {
+    __builtin_amdgcn_s_setprio(1);  // one dependent chain: issue ahead of the SIMD's other wave (see fused2d.hip)
     if constexpr (NT == 1) {
       accl::Sweep<16>::run(T, ubuf, lj, lk, bad, b);
     } else if constexpr (NT == 2) {
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(64, (NT == 3 ? 1 : 2)) void k_small_wave(Geo G, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[2][2][r] = sc[0][0][r];
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- prologue: every global load is issued before the first use ---------------------------------------------------------------------------
