@@ -446,6 +446,21 @@ __global__ __launch_bounds__(256) void k_left_mult_E(Geo G, const double* __rest
   }
 }
 
+// XCD-aware ids for the strip kernels: the n workgroups (mesh rows) of one (row block, cell) unit read each other's input segments, so they
+// should share an L2, i.e. sit on ONE XCD.  Workgroups go to the XCDs round-robin by linear id: linear id L -> XCD L % 8, mesh row
+// (L / 8) % n, unit 8 (L / (8 n)) + L % 8.  (With mesh row = blockIdx.x the n neighbours landed on n different XCDs and every segment was
+// fetched from HBM three times.)
+__device__ __forceinline__ bool strip_ids(int n, int yblocks, long long nunits, int& jrow, int& by, long long& cell) {
+  const unsigned L = blockIdx.x;
+  const long long unit = 8ll * (L / (8u * n)) + (L & 7u);
+  jrow = (int)((L >> 3) % (unsigned)n);
+  if (unit >= nunits) return false;
+  by = (int)(unit % yblocks);
+  cell = unit / yblocks;
+  return true;
+}
+inline unsigned strip_grid(int n, long long nunits) { return (unsigned)(((nunits + 7) / 8) * 8 * n); }
+
 // Same product for 3D planes with n <= 16: one workgroup per MESH ROW of the plane (n nodes, n BSV output rows) and
 // 32-column chunks.  The 3 n BSV input rows the strip depends on (mesh rows j-1, j, j+1) are staged through LDS once
 // per chunk -- 3x read amplification instead of the 9x of the node-per-workgroup kernel -- with the next chunk in flight
@@ -453,14 +468,16 @@ __global__ __launch_bounds__(256) void k_left_mult_E(Geo G, const double* __rest
 template <int BSV>
 __global__ __launch_bounds__(256, 3) void k_left_mult_E_strip(Geo G, const double* __restrict__ Kst,
                                                            const double* __restrict__ X, double* __restrict__ OUT,
-                                                           int rowPlane, double alpha) {
+                                                           int rowPlane, double alpha, long long ncells) {
   constexpr int CW = 32, NN = 9, SLMAX = 16 * BSV, LPT = (SLMAX * CW + 255) / 256;  // loads per thread per segment
   constexpr int NEB = NN * BSV * BSV;
   __shared__ double xs[3][SLMAX][CW];
   __shared__ double es[16][NEB];  // E of the strip's nodes: [node][neighbour][be][al]  (read as 16-lane broadcasts)
   const int tid = threadIdx.x, i = tid >> 4, cp = tid & 15;
-  const int n = G.n, jrow = blockIdx.x, SL = n * BSV, Bp = G.Bp;
-  const long long cell = blockIdx.z;
+  const int n = G.n, SL = n * BSV, Bp = G.Bp;
+  int jrow, by_;
+  long long cell;
+  if (!strip_ids(n, 1, ncells, jrow, by_, cell)) return;
   const long long per = (long long)Bp * Bp;
   const double* x = X + cell * per;
   double* out = OUT + cell * per;
@@ -553,16 +570,18 @@ template <int BSV>
 __global__ __launch_bounds__(256, 2) void k_right_mult_Et_strip(Geo G, const double* __restrict__ Kst,
                                                                 const double* __restrict__ IN, double* __restrict__ OUT,
                                                                 int nrows, int rowPlane, double alpha, int codeOff,
-                                                                int accumulate, int rowsPerBlock) {
+                                                                int accumulate, int rowsPerBlock, int yblocks, long long ncells) {
   constexpr int CW = 32, CWP = 34, NN = 9, SLMAX = 16 * BSV;
   constexpr int NEB = NN * BSV * BSV;
   __shared__ alignas(16) double xs[3][SLMAX][CWP];
   __shared__ double es[16][NEB];
   __shared__ double ob[CW][SLMAX + 1];
   const int tid = threadIdx.x, i = tid >> 4, rp = tid & 15;
-  const int n = G.n, jrow = blockIdx.x, SL = n * BSV, Bp = G.Bp;
-  const long long cell = blockIdx.z;
-  const int kbeg = blockIdx.y * rowsPerBlock, kend = min(nrows, kbeg + rowsPerBlock);
+  const int n = G.n, SL = n * BSV, Bp = G.Bp;
+  int jrow, by;
+  long long cell;
+  if (!strip_ids(n, yblocks, (long long)yblocks * ncells, jrow, by, cell)) return;
+  const int kbeg = by * rowsPerBlock, kend = min(nrows, kbeg + rowsPerBlock);
   if (kbeg >= kend) return;
   const long long per = (long long)nrows * Bp;
   const double* in = IN + cell * per;
@@ -1223,11 +1242,12 @@ void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int r
   if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !c.ws->sparse_v1) {  // strip kernel (HOMMX_SPARSE_V1: dev knob, generic kernels)
     int rpb = (nrows + 31) / 32 * 32;  // rows per workgroup: as many as still leave ~4 workgroups per slot
     while (rpb > 32 && (long long)((nrows + rpb - 1) / rpb) * c.nc * G.n < 4096) rpb = (rpb / 2 + 31) / 32 * 32;
-    dim3 g2((unsigned)G.n, (nrows + rpb - 1) / rpb, (unsigned)c.nc);
+    const int yb = (nrows + rpb - 1) / rpb;
+    dim3 g2(strip_grid(G.n, (long long)yb * c.nc));
     if (G.bs == 1)
-      hipLaunchKernelGGL((k_right_mult_Et_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
+      hipLaunchKernelGGL((k_right_mult_Et_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb, yb, c.nc);
     else
-      hipLaunchKernelGGL((k_right_mult_Et_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb);
+      hipLaunchKernelGGL((k_right_mult_Et_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate, rpb, yb, c.nc);
     return;
   }
 #define HOMMX_RM(BSV, NE) hipLaunchKernelGGL((k_right_mult_Et<BSV, NE, RT>), grid, block, 0, c.st, G, c.ws->Kst, IN, OUT, nrows, rowPlane, alpha, codeOff, accumulate)
@@ -1243,9 +1263,9 @@ void left_mult_E(const Ctx& c, const double* X, double* OUT, int rowPlane, doubl
   dim3 grid((G.Bp + G.bs - 1) / G.bs, 1, (unsigned)c.nc), block(256);
   const int ne = G.bs * (G.ncode / 3);
   if (G.dim == 3 && G.n <= 16 && (G.bs == 1 || G.bs == 3) && !c.ws->sparse_v1) {  // strip kernel
-    dim3 g2((unsigned)G.n, 1, (unsigned)c.nc);
-    if (G.bs == 1) hipLaunchKernelGGL((k_left_mult_E_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha);
-    else hipLaunchKernelGGL((k_left_mult_E_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha);
+    dim3 g2(strip_grid(G.n, c.nc));
+    if (G.bs == 1) hipLaunchKernelGGL((k_left_mult_E_strip<1>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha, c.nc);
+    else hipLaunchKernelGGL((k_left_mult_E_strip<3>), g2, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha, c.nc);
     return;
   }
 #define HOMMX_LM(BSV, NE) hipLaunchKernelGGL((k_left_mult_E<BSV, NE>), grid, block, 0, c.st, G, c.ws->Kst, X, OUT, rowPlane, alpha)
