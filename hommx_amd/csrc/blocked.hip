@@ -885,6 +885,7 @@ struct BlockedWorkspace {
   int gemm128_min = 256;       // HOMMX_GEMM128_MIN
   bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
   bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
+  bool split64 = true;         // HOMMX_NO_SPLIT64: halve 192 into 96 + 96 (32- and 64-leaves) instead of 64 + 128
   bool small_fused = true;     // HOMMX_NO_SMALL_FUSED switches the LDS-resident kernel for b <= 64 off (A/B runs)
   int small_waves = 0;         // HOMMX_SMALL_WAVES: 2 / 4 = the LDS kernel with that many waves per macro cell; 0 = default routes
   long long chunk = 0;
@@ -962,6 +963,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   if (const char* e = getenv("HOMMX_GEMM128_MIN")) ws->gemm128_min = atoi(e);
   ws->sparse_v1 = getenv("HOMMX_SPARSE_V1") != nullptr;
   ws->leaf32 = getenv("HOMMX_LEAF32") != nullptr;
+  ws->split64 = getenv("HOMMX_NO_SPLIT64") == nullptr;
   ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
   if (const char* e = getenv("HOMMX_SMALL_WAVES")) ws->small_waves = atoi(e);
   *out = ws;
@@ -1295,6 +1297,7 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
   }
   int s1 = (size / 2) / 32 * 32;
   if (s1 < 32) s1 = 32;
+  if (c.ws->split64 && size >= 128 && size % 64 == 0) s1 = (size / 2) / 64 * 64;  // 192 -> 64 + 128: every leaf a 64-block, whole 64-tiles
   const int s2 = size - s1;
   double* A11 = S + (long long)off * ld + off;
   double* A21 = S + (long long)(off + s1) * ld + off;
