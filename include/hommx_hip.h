@@ -50,7 +50,8 @@ extern "C" {
  *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the one-launch kernels
  *   HOMMX_SMALL_WAVES      2 / 4: plane blocks b <= 48 take the LDS-resident multi-wave kernel (that many waves per macro cell)
- *                          instead of the one-wave-per-cell register kernel; for 48 < b <= 64 it sets that kernel's wave count  */
+ *                          instead of the one-wave-per-cell register kernel; for 48 < b <= 64 it sets that kernel's wave count
+ *                          (2 / 4 / 8, default 8)                                                                              */
 
 typedef struct hommx_plan hommx_plan;
 
