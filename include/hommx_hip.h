@@ -47,6 +47,7 @@ extern "C" {
  *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256)
  *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products
  *   HOMMX_LEAF32           any value: 32x32 leaves only in the recursive block inverse
+ *   HOMMX_NO_SPLIT64       any value: the recursive block inverse halves 192 into 96 + 96 instead of 64 + 128
  *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the one-launch kernels
  *   HOMMX_SMALL_WAVES      2 / 4: plane blocks b <= 48 take the LDS-resident multi-wave kernel (that many waves per macro cell)
