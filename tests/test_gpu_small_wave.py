@@ -30,6 +30,8 @@ CASES = [
     ("elasticity", 2, 21),        # b 42, t 3: NT 3, bordered, 11 of 12 slabs
     ("elasticity", 3, 4),         # b 48, t 6: NT 3, slab form
     ("poisson_matrix", 2, 47),    # b 47, t 2: NT 3, slab form (b + t = 49)
+    ("poisson", 3, 7),            # b 49: LDS kernel (48 < b <= 64, csrc/small_fused.h), 13 of 16 k-slabs
+    ("elasticity", 2, 28),        # b 56: LDS kernel, 14 of 16 k-slabs
 ]
 
 
