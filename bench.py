@@ -113,6 +113,42 @@ def cpu_baseline(coef: np.ndarray, n: int, vols_X: np.ndarray, budget_s: float =
     return done / dt, done
 
 
+def cpu_baseline_c5(shape, n: int, cells: np.ndarray):
+    """Reference-shaped CPU path for C5 (oracle, one core): hmm.py:334-369 for the given macro cells -- 12 corrector solves on the
+    12,288-unknown periodic elasticity problem (SciPy splu) + 144 energies per cell, about half a minute each."""
+    from hommx_amd import workloads
+    from oracle import hommx_oracle as O
+
+    msh, mask, values, M = workloads.c5_two_phase(shape, n, cells=cells)
+    X = msh.cell_vertices()[cells]
+    t0 = time.perf_counter()
+    for k in range(len(cells)):
+        coef = np.where(mask[:, None], values[k, 1][None, :], values[k, 0][None, :])  # [n_el, (lambda, mu)]
+        O.local_stiffness_reference_shaped("elasticity", 3, n, X[k], coef, 2.0**-8, M[k])
+    dt = time.perf_counter() - t0
+    return len(cells) / dt, len(cells)
+
+
+def cpu_baseline_c5_multicore(args, n_sample: int):
+    """"C4/C5 CPU: time a fixed subsample (first 8 cells) and extrapolate linearly".  One cell per process, side by
+    side; rate = cells / the slowest worker's time."""
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config", "C5", "--cpu-worker", str(w), "1", "--micro",
+                              str(args.micro), "--c5-shape"] + [str(v) for v in args.c5_shape], stdout=subprocess.PIPE, text=True, env=env)
+            for w in range(n_sample)]
+    done, slowest = 0, 0.0
+    for k in kids:
+        out, _ = k.communicate(timeout=900)
+        r = json.loads(out.strip().splitlines()[-1])
+        done += r["done"]
+        slowest = max(slowest, r["seconds"])
+    return done / slowest, done, slowest
+
+
 def cpu_worker(args):
     """Child process of the multi-core CPU baseline: `bench.py --cpu-worker START COUNT` runs the one-core loop on its own
     slice of the same workload (the reference partitions the macro cells over MPI ranks the same way, hmm.py:307-310)
@@ -120,6 +156,10 @@ def cpu_worker(args):
     from hommx_amd import workloads
 
     start, count = args.cpu_worker
+    if args.config == "C5":
+        rate, done = cpu_baseline_c5(tuple(args.c5_shape), args.micro, np.arange(start, start + count))
+        print(json.dumps({"done": done, "seconds": done / rate}))
+        return
     msh, coef_h, _ = workloads.c2_inclusion(args.macro, args.micro)
     X = msh.cell_vertices()
     rate, done = cpu_baseline(coef_h[start : start + count], args.micro, X[start : start + count], args.cpu_budget)
@@ -148,6 +188,107 @@ def cpu_baseline_multicore(args, coef_h, n, X, cores: int):
         done += r["done"]
         slowest = max(slowest, r["seconds"])
     return done / slowest, done, rate0
+
+
+def launch_mode(gpus: int, env, visible_devices) -> str:
+    """How `bench.py --gpus N` must run (the reference's only parallel strategy is N ranks, each owning a macro partition:
+    hmm.py:307-310, docs/usage/usage.md:64-71).  Returns "inline" (this process is the one rank, or one rank of a launcher's
+    N) or "spawn" (plain `python bench.py --gpus N`: this process starts the N ranks itself).  Raises SystemExit -- never a
+    silent run on fewer GPUs -- when the launcher's WORLD_SIZE disagrees with --gpus or fewer than N devices are visible.
+    `visible_devices` is a callable so that nothing touches the GPU before the children exist."""
+    if gpus < 1:
+        raise SystemExit(f"--gpus {gpus}: need at least one GPU")
+    launched = "RANK" in env or "WORLD_SIZE" in env
+    if launched:
+        world = int(env.get("WORLD_SIZE", "1"))
+        if world != gpus:
+            raise SystemExit(f"--gpus {gpus} but the launcher set WORLD_SIZE={world}: refusing to report {world} rank(s) as {gpus} GPUs")
+        return "inline"
+    if gpus == 1:
+        return "inline"
+    have = int(visible_devices())
+    if have < gpus:
+        raise SystemExit(f"--gpus {gpus} but only {have} device(s) visible: refusing to run on fewer GPUs than asked for")
+    return "spawn"
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(gpus: int, argv: list[str]) -> int:
+    """Start `gpus` ranks of this script as CHILD processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, exactly what torch.distributed.run would set), relay rank 0's JSON line, return non-zero if any rank
+    failed.  The parent never initialises the GPU and never execs: the ranks are ordinary children."""
+    import subprocess
+
+    port = _free_port()
+    kids = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                     stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = kids[0].communicate()
+    rcs = [kids[0].returncode]
+    for k in kids[1:]:
+        try:
+            rcs.append(k.wait(timeout=300))
+        except subprocess.TimeoutExpired:  # rank 0 is gone: a survivor would wait in a collective for ever
+            k.kill()
+            rcs.append(-9)
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if any(rcs) or line is None:
+        print(f"[bench] ranks exited with {rcs}" + ("" if line else "; rank 0 printed no JSON line"), file=sys.stderr)
+        return 1
+    rec = json.loads(line)
+    if rec.get("n_gpus") != gpus:
+        print(f"[bench] asked for {gpus} GPUs, line says n_gpus={rec.get('n_gpus')}", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def dry_run(args):
+    """Launcher rehearsal WITHOUT a GPU (hidden flag --dry-run-cpu, used by tests/test_bench_launch.py): gloo ranks, the plan
+    replaced by a stub that writes the rank into its shard; the emitted line has the contract's keys with value = null and
+    "data": "dry-run", so it can never pass for a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = "RANK" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hommx_amd.dist import all_gather_field, shard_range
+
+    if args.config == "C5":
+        ntot = 6 * args.c5_shape[0] * args.c5_shape[1] * args.c5_shape[2]
+        b, e, per = shard_range(ntot, rank, world)
+        t, scaling = 6, "strong"
+    else:
+        per = 2 * args.macro * args.macro
+        b, e, ntot, t, scaling = rank * per, (rank + 1) * per, world * per, 2, "weak"
+    out = torch.zeros(per, t, t, dtype=torch.float64)
+    out[: e - b] = float(rank + 1)
+    field = all_gather_field(out, world * per) if use_dist else out
+    owners = sorted({int(v) for v in field[:, 0, 0].tolist() if v > 0})
+    if rank == 0:
+        print(json.dumps({"metric": "micro-cell solves/sec", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": scaling,
+                          "vs_baseline": None, "dtype": "f64", "data": "dry-run", "dry_run": True,
+                          "config": {"workload": f"{args.config} launcher rehearsal on gloo, no kernel", "cells_total": ntot},
+                          "ranks_seen_in_gathered_field": owners}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def timed_steps(step, steps, warmup, use_dist, dist, dev, torch):
@@ -191,6 +332,8 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0: min(16, available))")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work per core")
     ap.add_argument("--cpu-worker", type=int, nargs=2, metavar=("START", "COUNT"), help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)  # launcher rehearsal on gloo (tests)
+    ap.add_argument("--dry-run-devices", type=int, default=None, help=argparse.SUPPRESS)  # pretended device count (tests)
     args = ap.parse_args()
     if args.micro is None:
         args.micro = 32 if args.config == "C2" else 16
@@ -200,6 +343,18 @@ def main():
         args.warmup = 20 if args.config == "C2" else 0
     if args.cpu_worker:
         return cpu_worker(args)
+
+    def visible_devices():
+        if args.dry_run_devices is not None:
+            return args.dry_run_devices
+        import torch  # device_count() does not initialise the GPU on this image
+
+        return torch.cuda.device_count()
+
+    if launch_mode(args.gpus, os.environ, visible_devices) == "spawn":
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run_cpu:
+        return dry_run(args)
 
     # stdout carries ONE JSON line: native libraries that chat on fd 1 (RCCL prints a version banner at communicator creation)
     # are sent to stderr for the duration of the run
@@ -218,8 +373,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert world == args.gpus  # launch_mode() has made sure
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -464,7 +618,23 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
     achieved = F * nloc / (kern_ms * 1e-3)
     C = field[:nloc].cpu().numpy()
     sym = float(np.abs(C - np.transpose(C, (0, 2, 1))).max() / np.abs(C).max())
-    return {
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        avail = usable_cores()
+        n_sample = max(1, min(8, avail, ntot))
+        rate, done, slowest = cpu_baseline_c5_multicore(args, n_sample)
+        cpu = {
+            "value": rate,
+            "unit": "solves/s",
+            "cores": n_sample,
+            "per_core": rate / n_sample,
+            "kind": "port",
+            "sample": f"the first {done} macro cells of the same workload, one process per cell side by side ({slowest:.0f} s for the slowest), "
+            "extrapolated linearly to the batch (SURVEY 8(d)); the timed loop holds only the oracle restatement of hmm.py:334-369 "
+            "(12 corrector solves on 12,288 unknowns with SciPy splu + 144 energies per cell); host cores usable by this process: "
+            f"{avail}",
+        }
+    rec = {
         "metric": "micro-cell solves/sec",
         "value": ntot * args.steps / dt,
         "unit": "solves/s",
@@ -505,6 +675,9 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
         "info_nonzero": n_bad,
         "symmetry_defect": sym,
     }
+    if cpu is not None:
+        rec["cpu_baseline"] = cpu
+    return rec
 
 
 if __name__ == "__main__":
