@@ -18,6 +18,9 @@ EXPORTED_SYMBOLS = (
     "hommx_plan_create",
     "hommx_plan_destroy",
     "hommx_plan_dim",
+    "hommx_plan_device",
+    "hommx_plan_n_micro",
+    "hommx_plan_kind",
     "hommx_plan_num_elements",
     "hommx_plan_coef_components",
     "hommx_plan_tensor_size",
@@ -34,6 +37,10 @@ EXPORTED_SYMBOLS = (
     "hommx_comm_size",
     "hommx_allgather_field",
     "hommx_solve_batch_multi",
+    "hommx_solve_batch_multi_device",
+    "hommx_shard_range",
+    "hommx_unpack_field",
+    "hommx_calibrate_fp64",
     "hommx_calibrate_fp64_mfma",
     "hommx_last_error",
 )
@@ -132,8 +139,9 @@ def load():
     lib.hommx_solve_batch_separable.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.hommx_solve_batch_separable_device.restype = C.c_int
     lib.hommx_solve_batch_separable_device.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-    lib.hommx_plan_dim.restype = i32
-    lib.hommx_plan_dim.argtypes = [vp]
+    for q in ("hommx_plan_dim", "hommx_plan_device", "hommx_plan_n_micro", "hommx_plan_kind"):
+        getattr(lib, q).restype = i32
+        getattr(lib, q).argtypes = [vp]
     lib.hommx_comm_init_all.restype = C.c_int
     lib.hommx_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
     lib.hommx_comm_destroy.restype = C.c_int
@@ -144,6 +152,15 @@ def load():
     lib.hommx_allgather_field.argtypes = [vp, C.POINTER(vp), i64]
     lib.hommx_solve_batch_multi.restype = C.c_int
     lib.hommx_solve_batch_multi.argtypes = [vp, C.POINTER(vp), i64, vp, vp, vp, vp]
+    lib.hommx_solve_batch_multi_device.restype = C.c_int
+    lib.hommx_solve_batch_multi_device.argtypes = [vp, C.POINTER(vp), i64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    i64p = C.POINTER(i64)
+    lib.hommx_shard_range.restype = C.c_int
+    lib.hommx_shard_range.argtypes = [i64, i32, i32, i64p, i64p, i64p]
+    lib.hommx_unpack_field.restype = C.c_int
+    lib.hommx_unpack_field.argtypes = [i64, i32, i32, vp, vp, vp]
+    lib.hommx_calibrate_fp64.restype = C.c_int
+    lib.hommx_calibrate_fp64.argtypes = [C.c_int, dp, dp]
     lib.hommx_calibrate_fp64_mfma.restype = C.c_int
     lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
     lib.hommx_last_error.restype = C.c_char_p

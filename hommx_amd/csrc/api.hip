@@ -40,6 +40,20 @@ enum Family { FAM_FUSED2D = 0, FAM_BLOCKED = 1 };
 
 }  // namespace
 
+struct hommx_plan;
+namespace {
+template <typename B>
+int grow(B& b, size_t bytes) {
+  if (bytes <= b.cap) return HOMMX_OK;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  HIP_TRY(hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return HOMMX_OK;
+}
+}  // namespace
+
 struct hommx_plan {
   hommx_plan_desc desc;
   Family family;
@@ -55,6 +69,12 @@ struct hommx_plan {
   hommx::BlockedWorkspace* ws = nullptr;
   double* d_expand = nullptr;  // two-phase media on the blocked family: expanded element stream
   int64_t cap_expand = 0;
+  // plan-owned staging of the sampler entry points (two-phase / separable, host pointers): grown on demand, never per call
+  struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+  };
+  Buf st_mask, st_values, st_table, st_w, st_M, st_out, st_info;
   // host-pointer entry point of the fused family: coefficient chunks stream in on s_copy while s_comp solves the previous one
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -116,6 +136,8 @@ int hommx_plan_destroy(hommx_plan* p) {
   if (p->d_info) hipFree(p->d_info);
   if (p->ws) hommx::blocked_workspace_destroy(p->ws);
   if (p->d_expand) hipFree(p->d_expand);
+  for (hommx_plan::Buf* b : {&p->st_mask, &p->st_values, &p->st_table, &p->st_w, &p->st_M, &p->st_out, &p->st_info})
+    if (b->p) hipFree(b->p);
   if (p->s_copy) hipStreamDestroy(p->s_copy);
   if (p->s_comp) hipStreamDestroy(p->s_comp);
   for (hipEvent_t e : p->ev)
@@ -128,12 +150,15 @@ int hommx_plan_destroy(hommx_plan* p) {
 int hommx_set_error_(int code, const char* msg) { return fail(code, "%s", msg); }
 
 int32_t hommx_plan_dim(const hommx_plan* p) { return p ? p->desc.dim : 0; }
+int32_t hommx_plan_device(const hommx_plan* p) { return p ? p->desc.device : -1; }
+int32_t hommx_plan_n_micro(const hommx_plan* p) { return p ? p->desc.n_micro : 0; }
+int32_t hommx_plan_kind(const hommx_plan* p) { return p ? p->desc.kind : -1; }
 int64_t hommx_plan_num_elements(const hommx_plan* p) { return p ? p->n_el : 0; }
 int32_t hommx_plan_coef_components(const hommx_plan* p) { return p ? p->n_comp : 0; }
 int32_t hommx_plan_tensor_size(const hommx_plan* p) { return p ? p->t : 0; }
 const char* hommx_plan_kernel_name(const hommx_plan* p) {
   if (!p) return "";
-  return p->family == FAM_FUSED2D ? "fused2d" : "blocked";
+  return p->family == FAM_FUSED2D ? "fused2d" : hommx::blocked_route_name(p->ws);
 }
 
 int hommx_solve_batch_device(hommx_plan* p, int64_t n_cells, const double* d_coef, const double* d_M,
@@ -258,45 +283,22 @@ int hommx_solve_batch_two_phase(hommx_plan* p, int64_t n_cells, const uint8_t* m
   if (!mask || !values || !A_eff) return fail(HOMMX_EINVAL, "null mask / values / A_eff");
   HIP_TRY(hipSetDevice(p->desc.device));
   const int d = p->desc.dim, t = p->t;
-  unsigned char* d_mask = nullptr;
-  double *d_values = nullptr, *d_M = nullptr, *d_out = nullptr;
-  int32_t* d_info = nullptr;
-  auto cleanup = [&]() {
-    if (d_mask) hipFree(d_mask);
-    if (d_values) hipFree(d_values);
-    if (d_M) hipFree(d_M);
-    if (d_out) hipFree(d_out);
-    if (d_info) hipFree(d_info);
-  };
-#define HIP_TRY_C(expr)                                                                             \
-  do {                                                                                              \
-    hipError_t e__ = (expr);                                                                        \
-    if (e__ != hipSuccess) {                                                                        \
-      cleanup();                                                                                    \
-      return fail(e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP, "%s failed: %s", #expr,   \
-                  hipGetErrorString(e__));                                                          \
-    }                                                                                               \
-  } while (0)
-  HIP_TRY_C(hipMalloc(&d_mask, p->n_el));
-  HIP_TRY_C(hipMalloc(&d_values, sizeof(double) * n_cells * 2 * p->n_comp));
-  HIP_TRY_C(hipMalloc(&d_out, sizeof(double) * n_cells * t * t));
-  HIP_TRY_C(hipMalloc(&d_info, sizeof(int32_t) * n_cells));
-  HIP_TRY_C(hipMemcpy(d_mask, mask, p->n_el, hipMemcpyHostToDevice));
-  HIP_TRY_C(hipMemcpy(d_values, values, sizeof(double) * n_cells * 2 * p->n_comp, hipMemcpyHostToDevice));
-  if (M) {
-    HIP_TRY_C(hipMalloc(&d_M, sizeof(double) * n_cells * d * d));
-    HIP_TRY_C(hipMemcpy(d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
-  }
-  int rc = hommx_solve_batch_two_phase_device(p, n_cells, d_mask, d_values, d_M, d_out, d_info, nullptr);
-  if (rc != HOMMX_OK) {
-    cleanup();
-    return rc;
-  }
-  HIP_TRY_C(hipDeviceSynchronize());
-  HIP_TRY_C(hipMemcpy(A_eff, d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
-  if (info) HIP_TRY_C(hipMemcpy(info, d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
-#undef HIP_TRY_C
-  cleanup();
+  // staging lives in the plan (grown on demand): no hipMalloc / hipFree per call
+  if (int rc = grow(p->st_mask, (size_t)p->n_el)) return rc;
+  if (int rc = grow(p->st_values, sizeof(double) * n_cells * 2 * p->n_comp)) return rc;
+  if (int rc = grow(p->st_out, sizeof(double) * n_cells * t * t)) return rc;
+  if (int rc = grow(p->st_info, sizeof(int32_t) * n_cells)) return rc;
+  if (M)
+    if (int rc = grow(p->st_M, sizeof(double) * n_cells * d * d)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->st_mask.p, mask, p->n_el, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(p->st_values.p, values, sizeof(double) * n_cells * 2 * p->n_comp, hipMemcpyHostToDevice, nullptr));
+  if (M) HIP_TRY(hipMemcpyAsync(p->st_M.p, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice, nullptr));
+  int rc = hommx_solve_batch_two_phase_device(p, n_cells, static_cast<const uint8_t*>(p->st_mask.p), static_cast<const double*>(p->st_values.p),
+                                              M ? static_cast<const double*>(p->st_M.p) : nullptr, static_cast<double*>(p->st_out.p),
+                                              static_cast<int32_t*>(p->st_info.p), nullptr);
+  if (rc != HOMMX_OK) return rc;
+  HIP_TRY(hipMemcpy(A_eff, p->st_out.p, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));  // default stream: after the kernel
+  if (info) HIP_TRY(hipMemcpy(info, p->st_info.p, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
   return HOMMX_OK;
 }
 
@@ -351,53 +353,31 @@ int hommx_solve_batch_separable(hommx_plan* p, int64_t n_cells, int32_t family, 
   if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
   if (n_cells == 0) return HOMMX_OK;
   if (!table || !params || !A_eff) return fail(HOMMX_EINVAL, "null table / params / A_eff");
+  if (family != HOMMX_SAMPLER_AFFINE && family != HOMMX_SAMPLER_RECIPROCAL) return fail(HOMMX_EINVAL, "unknown sampler family %d", family);
   if (family == HOMMX_SAMPLER_RECIPROCAL && (n_q < 1 || !weights)) return fail(HOMMX_EINVAL, "reciprocal sampler needs n_q >= 1 and weights");
   HIP_TRY(hipSetDevice(p->desc.device));
   const int d = p->desc.dim, t = p->t;
   const int64_t ntab = p->n_el * (family == HOMMX_SAMPLER_AFFINE ? 1 : n_q);
-  double *d_table = nullptr, *d_w = nullptr, *d_params = nullptr, *d_M = nullptr, *d_out = nullptr;
-  int32_t* d_info = nullptr;
-  auto cleanup = [&]() {
-    if (d_table) hipFree(d_table);
-    if (d_w) hipFree(d_w);
-    if (d_params) hipFree(d_params);
-    if (d_M) hipFree(d_M);
-    if (d_out) hipFree(d_out);
-    if (d_info) hipFree(d_info);
-  };
-#define HIP_TRY_C(expr)                                                                             \
-  do {                                                                                              \
-    hipError_t e__ = (expr);                                                                        \
-    if (e__ != hipSuccess) {                                                                        \
-      cleanup();                                                                                    \
-      return fail(e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP, "%s failed: %s", #expr,   \
-                  hipGetErrorString(e__));                                                          \
-    }                                                                                               \
-  } while (0)
-  HIP_TRY_C(hipMalloc(&d_table, sizeof(double) * ntab));
-  HIP_TRY_C(hipMalloc(&d_params, sizeof(double) * n_cells * 2));
-  HIP_TRY_C(hipMalloc(&d_out, sizeof(double) * n_cells * t * t));
-  HIP_TRY_C(hipMalloc(&d_info, sizeof(int32_t) * n_cells));
-  HIP_TRY_C(hipMemcpy(d_table, table, sizeof(double) * ntab, hipMemcpyHostToDevice));
-  HIP_TRY_C(hipMemcpy(d_params, params, sizeof(double) * n_cells * 2, hipMemcpyHostToDevice));
-  if (weights && n_q > 0) {
-    HIP_TRY_C(hipMalloc(&d_w, sizeof(double) * n_q));
-    HIP_TRY_C(hipMemcpy(d_w, weights, sizeof(double) * n_q, hipMemcpyHostToDevice));
-  }
-  if (M) {
-    HIP_TRY_C(hipMalloc(&d_M, sizeof(double) * n_cells * d * d));
-    HIP_TRY_C(hipMemcpy(d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
-  }
-  int rc = hommx_solve_batch_separable_device(p, n_cells, family, n_q, d_table, d_w, d_params, d_M, d_out, d_info, nullptr);
-  if (rc != HOMMX_OK) {
-    cleanup();
-    return rc;
-  }
-  HIP_TRY_C(hipDeviceSynchronize());
-  HIP_TRY_C(hipMemcpy(A_eff, d_out, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
-  if (info) HIP_TRY_C(hipMemcpy(info, d_info, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
-#undef HIP_TRY_C
-  cleanup();
+  const bool has_w = weights && n_q > 0;
+  if (int rc = grow(p->st_table, sizeof(double) * ntab)) return rc;
+  if (int rc = grow(p->st_values, sizeof(double) * n_cells * 2)) return rc;
+  if (int rc = grow(p->st_out, sizeof(double) * n_cells * t * t)) return rc;
+  if (int rc = grow(p->st_info, sizeof(int32_t) * n_cells)) return rc;
+  if (has_w)
+    if (int rc = grow(p->st_w, sizeof(double) * n_q)) return rc;
+  if (M)
+    if (int rc = grow(p->st_M, sizeof(double) * n_cells * d * d)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->st_table.p, table, sizeof(double) * ntab, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(p->st_values.p, params, sizeof(double) * n_cells * 2, hipMemcpyHostToDevice, nullptr));
+  if (has_w) HIP_TRY(hipMemcpyAsync(p->st_w.p, weights, sizeof(double) * n_q, hipMemcpyHostToDevice, nullptr));
+  if (M) HIP_TRY(hipMemcpyAsync(p->st_M.p, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice, nullptr));
+  int rc = hommx_solve_batch_separable_device(p, n_cells, family, n_q, static_cast<const double*>(p->st_table.p),
+                                              has_w ? static_cast<const double*>(p->st_w.p) : nullptr, static_cast<const double*>(p->st_values.p),
+                                              M ? static_cast<const double*>(p->st_M.p) : nullptr, static_cast<double*>(p->st_out.p),
+                                              static_cast<int32_t*>(p->st_info.p), nullptr);
+  if (rc != HOMMX_OK) return rc;
+  HIP_TRY(hipMemcpy(A_eff, p->st_out.p, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));
+  if (info) HIP_TRY(hipMemcpy(info, p->st_info.p, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
   return HOMMX_OK;
 }
 
@@ -458,11 +438,13 @@ int hommx_solve_batch_correctors(hommx_plan* p, int64_t n_cells, const double* c
   return HOMMX_OK;
 }
 
-int hommx_calibrate_fp64_mfma(int device, double* flops_per_s) {
-  if (!flops_per_s) return fail(HOMMX_EINVAL, "null argument");
+int hommx_calibrate_fp64(int device, double* mfma_flops_per_s, double* fma_flops_per_s) {
+  if (!mfma_flops_per_s && !fma_flops_per_s) return fail(HOMMX_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(device));
-  HIP_TRY(hommx::run_fp64_mfma_calibration(flops_per_s));
+  HIP_TRY(hommx::run_fp64_calibration(mfma_flops_per_s, fma_flops_per_s));
   return HOMMX_OK;
 }
+
+int hommx_calibrate_fp64_mfma(int device, double* flops_per_s) { return hommx_calibrate_fp64(device, flops_per_s, nullptr); }
 
 }  // extern "C"

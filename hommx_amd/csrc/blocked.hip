@@ -970,6 +970,12 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   return 0;
 }
 
+const char* blocked_route_name(const BlockedWorkspace* ws) {
+  if (!ws) return "blocked";
+  if (ws->G.b <= 64 && ws->small_fused) return (ws->G.b <= 48 && ws->small_waves != 2 && ws->small_waves != 4) ? "small_wave" : "small_fused";
+  return "blocked";
+}
+
 static void ws_free_main(BlockedWorkspace* ws) {
   double** ptrs[] = {&ws->Kst, &ws->Brhs, &ws->C0, &ws->S, &ws->W, &ws->Sl, &ws->V, &ws->X, &ws->T, &ws->R, &ws->Rl, &ws->Vr, &ws->Gm};
   for (auto p : ptrs) {

@@ -1,5 +1,8 @@
-// calibrate.hip -- fp64 MFMA peak calibration (the local hardware guide lists no fp64 matrix rate;
-// SURVEY.md section 7 asks for a micro-benchmark before quoting a roofline fraction).
+// calibrate.hip -- measured fp64 peak of the device (the local hardware guide lists no fp64 rate; SURVEY.md section 7 asks
+// for a micro-benchmark before a roofline fraction is quoted).  Two dependent-chain-free loops, v_mfma_f64_16x16x4_f64 with
+// 8 independent accumulator tiles per wave and v_fma_f64 with 16 independent accumulators per lane, each at 2 and 4 waves per
+// SIMD; the best rate of each instruction is reported.  On MI355X both instructions share ONE fp64 FMA pipe (DESIGN.md
+// section 5), so the larger of the two figures is the measured peak a kernel mixing them can be priced against.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -23,7 +26,38 @@ __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* sink, int iters) 
   if (s == 123.456) sink[0] = s;  // keep the chain alive
 }
 
-hipError_t run_fp64_mfma_calibration(double* flops_per_s) {
+__global__ __launch_bounds__(256) void k_fma_f64_peak(double* sink, int iters) {
+  double a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = 1.0 + 1e-9 * (threadIdx.x + i);
+  const double b = 1.0 + 1e-12 * threadIdx.x, c = 1e-13;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = fma(a[i], b, c);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += a[i];
+  if (s == 123.456) sink[0] = s;
+}
+
+template <typename K>
+static hipError_t time_loop(K kernel, double* sink, int blocks, int iters, float* ms) {
+  hipEvent_t t0, t1;
+  hipEventCreate(&t0);
+  hipEventCreate(&t1);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, sink, 200);  // warm-up
+  hipEventRecord(t0, 0);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, sink, iters);
+  hipEventRecord(t1, 0);
+  hipError_t e = hipEventSynchronize(t1);
+  hipEventElapsedTime(ms, t0, t1);
+  hipEventDestroy(t0);
+  hipEventDestroy(t1);
+  return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t run_fp64_calibration(double* mfma_flops_per_s, double* fma_flops_per_s) {
   double* sink = nullptr;
   hipError_t e = hipMalloc(&sink, 8);
   if (e != hipSuccess) return e;
@@ -31,25 +65,22 @@ hipError_t run_fp64_mfma_calibration(double* flops_per_s) {
   int dev = 0;
   hipGetDevice(&dev);
   hipGetDeviceProperties(&prop, dev);
-  const int blocks = prop.multiProcessorCount * 2;  // 8 waves per CU = 2 per SIMD
-  const int iters = 20000;
-  hipEvent_t t0, t1;
-  hipEventCreate(&t0);
-  hipEventCreate(&t1);
-  hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, 0, sink, 200);  // warm-up
-  hipEventRecord(t0, 0);
-  hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(256), 0, 0, sink, iters);
-  hipEventRecord(t1, 0);
-  e = hipEventSynchronize(t1);
-  float ms = 0.f;
-  hipEventElapsedTime(&ms, t0, t1);
-  hipEventDestroy(t0);
-  hipEventDestroy(t1);
+  double best_mfma = 0.0, best_fma = 0.0;
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep)
+    for (int wps : {2, 4}) {  // waves per SIMD: 256-thread blocks = 4 waves = one per SIMD of the CU
+      const int blocks = prop.multiProcessorCount * wps;
+      float ms = 0.f;
+      const int it_m = 20000, it_f = 40000;
+      if ((e = time_loop(k_mfma_f64_peak, sink, blocks, it_m, &ms)) != hipSuccess) break;
+      best_mfma = fmax(best_mfma, 2.0 * 16 * 16 * 4 * 8.0 * it_m * 4.0 * blocks / (ms * 1e-3));
+      if ((e = time_loop(k_fma_f64_peak, sink, blocks, it_f, &ms)) != hipSuccess) break;
+      best_fma = fmax(best_fma, 2.0 * 16.0 * it_f * 256.0 * blocks / (ms * 1e-3));
+    }
   hipFree(sink);
   if (e != hipSuccess) return e;
-  const double flops = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 * blocks;  // per MFMA x 8 x iters x waves
-  *flops_per_s = flops / (ms * 1e-3);
-  return hipGetLastError();
+  if (mfma_flops_per_s) *mfma_flops_per_s = best_mfma;
+  if (fma_flops_per_s) *fma_flops_per_s = best_fma;
+  return hipSuccess;
 }
 
 }  // namespace hommx

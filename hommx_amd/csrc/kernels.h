@@ -46,8 +46,8 @@ hipError_t launch_expand_separable(CoefSource src, const double* d_params, doubl
 hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_values, double* d_coef, long long n_el,
                                    int n_comp, long long ncells, hipStream_t stream);
 
-// calibrate.hip: sustained v_mfma_f64_16x16x4_f64 rate.
-hipError_t run_fp64_mfma_calibration(double* flops_per_s);
+// calibrate.hip: best sustained v_mfma_f64_16x16x4_f64 and v_fma_f64 rates over 2 and 4 waves per SIMD.
+hipError_t run_fp64_calibration(double* mfma_flops_per_s, double* fma_flops_per_s);
 
 }  // namespace hommx
 
@@ -59,4 +59,6 @@ void blocked_workspace_destroy(BlockedWorkspace* ws);
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M,
                   double* d_out, int32_t* d_info, hipStream_t stream, double* d_corr = nullptr);
 const char* blocked_last_error();
+// "small_wave" (b <= 48), "small_fused" (48 < b <= 64) or "blocked": the route blocked_solve takes for effective tensors
+const char* blocked_route_name(const BlockedWorkspace* ws);
 }  // namespace hommx

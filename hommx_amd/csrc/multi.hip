@@ -86,12 +86,41 @@ struct hommx_comm {
   std::vector<ncclComm_t> comms;
   std::vector<hipStream_t> streams;
   // scratch of hommx_solve_batch_multi, per device (grown on demand)
-  std::vector<double*> d_coef, d_M, d_field;
+  std::vector<double*> d_coef, d_M, d_field, d_packed;
   std::vector<int32_t*> d_info;
-  std::vector<int64_t> cap_cells, cap_field;
+  std::vector<int64_t> cap_cells, cap_field, cap_info;
 };
 
 extern "C" {
+
+int hommx_comm_destroy(hommx_comm* c);
+
+/* Contiguous block partition padded to equal counts: cells_i = [i * ceil(n / P), min(n, (i + 1) * ceil(n / P))).
+ * Pure host arithmetic -- the one place the shard bounds and the unpack offsets of the gathered field come from. */
+int hommx_shard_range(int64_t n_cells, int32_t ndev, int32_t i, int64_t* begin, int64_t* end, int64_t* per_dev) {
+  if (n_cells < 0 || ndev <= 0 || i < 0 || i >= ndev) return fail(HOMMX_EINVAL, "hommx_shard_range: bad arguments");
+  const int64_t per = (n_cells + ndev - 1) / ndev;
+  if (begin) *begin = std::min<int64_t>(n_cells, (int64_t)i * per);
+  if (end) *end = std::min<int64_t>(n_cells, (int64_t)(i + 1) * per);
+  if (per_dev) *per_dev = per;
+  return HOMMX_OK;
+}
+
+/* Unpack the gathered field  packed[ndev][per][t*t + 1]  (row = [A_eff | info as a double]) into A_eff[n_cells][t*t] and info. */
+int hommx_unpack_field(int64_t n_cells, int32_t ndev, int32_t tt, const double* packed, double* A_eff, int32_t* info) {
+  if (n_cells < 0 || ndev <= 0 || tt <= 0 || !packed || !A_eff) return fail(HOMMX_EINVAL, "hommx_unpack_field: bad arguments");
+  const int64_t row = tt + 1;
+  for (int i = 0; i < ndev; ++i) {
+    int64_t b, e, per;
+    hommx_shard_range(n_cells, ndev, i, &b, &e, &per);
+    for (int64_t k = b; k < e; ++k) {
+      const double* src = packed + ((int64_t)i * per + (k - b)) * row;
+      std::memcpy(A_eff + k * tt, src, sizeof(double) * tt);
+      if (info) info[k] = (int32_t)src[tt];
+    }
+  }
+  return HOMMX_OK;
+}
 
 int hommx_comm_init_all(hommx_comm** out, int ndev, const int* devs) {
   if (!out || ndev <= 0) return fail(HOMMX_EINVAL, "hommx_comm_init_all: bad arguments");
@@ -115,17 +144,30 @@ int hommx_comm_init_all(hommx_comm** out, int ndev, const int* devs) {
   c->d_coef.assign(ndev, nullptr);
   c->d_M.assign(ndev, nullptr);
   c->d_field.assign(ndev, nullptr);
+  c->d_packed.assign(ndev, nullptr);
   c->d_info.assign(ndev, nullptr);
   c->cap_cells.assign(ndev, 0);
   c->cap_field.assign(ndev, 0);
+  c->cap_info.assign(ndev, 0);
+  for (int i = 0; i < ndev; ++i)
+    for (int j = 0; j < i; ++j)
+      if (c->devs[i] == c->devs[j]) {
+        const int d = c->devs[i];
+        delete c;
+        return fail(HOMMX_EINVAL, "device %d listed twice (RCCL needs distinct devices)", d);
+      }
   ncclResult_t r = g_rccl.CommInitAll(c->comms.data(), ndev, c->devs.data());
   if (r != 0) {
     delete c;
     return fail(HOMMX_ERCCL, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
   }
   for (int i = 0; i < ndev; ++i) {
-    HIP_TRY(hipSetDevice(c->devs[i]));
-    HIP_TRY(hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking));
+    hipError_t e = hipSetDevice(c->devs[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams[i], hipStreamNonBlocking);
+    if (e != hipSuccess) {  // no leak: the streams made so far and the RCCL communicators go with the object
+      hommx_comm_destroy(c);
+      return fail(HOMMX_EHIP, "stream creation failed: %s", hipGetErrorString(e));
+    }
   }
   *out = c;
   return HOMMX_OK;
@@ -138,6 +180,7 @@ int hommx_comm_destroy(hommx_comm* c) {
     if (c->d_coef[i]) hipFree(c->d_coef[i]);
     if (c->d_M[i]) hipFree(c->d_M[i]);
     if (c->d_field[i]) hipFree(c->d_field[i]);
+    if (c->d_packed[i]) hipFree(c->d_packed[i]);
     if (c->d_info[i]) hipFree(c->d_info[i]);
     if (c->streams[i]) hipStreamDestroy(c->streams[i]);
     if (c->comms[i] && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comms[i]);
@@ -179,72 +222,144 @@ __global__ void k_pack_field(const double* __restrict__ A, const int32_t* __rest
   out[idx] = q < tt ? A[cell * tt + q] : (double)info[cell];
 }
 
+namespace {
+// plans[i] must live on device i of the communicator and all of them must describe the same problem
+int check_plans(const hommx_comm* c, hommx_plan* const* plans) {
+  for (int i = 0; i < c->ndev; ++i) {
+    if (!plans[i]) return fail(HOMMX_EINVAL, "null plan for device slot %d", i);
+    if (hommx_plan_device(plans[i]) != c->devs[i])
+      return fail(HOMMX_EINVAL, "plan %d lives on device %d, the communicator's slot %d is device %d", i, hommx_plan_device(plans[i]), i, c->devs[i]);
+    if (hommx_plan_dim(plans[i]) != hommx_plan_dim(plans[0]) || hommx_plan_n_micro(plans[i]) != hommx_plan_n_micro(plans[0]) ||
+        hommx_plan_kind(plans[i]) != hommx_plan_kind(plans[0]))
+      return fail(HOMMX_EINVAL, "plan %d differs from plan 0 in dim / n_micro / kind", i);
+  }
+  return HOMMX_OK;
+}
+
+// wait for what earlier devices already have in flight before an error leaves the function
+void drain(hommx_comm* c, int upto) {
+  for (int i = 0; i <= upto && i < c->ndev; ++i) {
+    if (hipSetDevice(c->devs[i]) == hipSuccess && c->streams[i]) (void)hipStreamSynchronize(c->streams[i]);
+  }
+}
+
+int ensure_field(hommx_comm* c, int i, int64_t need) {
+  if (need > c->cap_field[i]) {
+    if (c->d_field[i]) hipFree(c->d_field[i]);
+    c->d_field[i] = nullptr;
+    c->cap_field[i] = 0;
+    HIP_TRY(hipMalloc(&c->d_field[i], sizeof(double) * need));
+    c->cap_field[i] = need;
+  }
+  return HOMMX_OK;
+}
+}  // namespace
+
+int hommx_solve_batch_multi_device(hommx_comm* c, hommx_plan* const* plans, int64_t n_cells, const double* const* d_coef_per_dev,
+                                   const double* const* d_M_per_dev, double* const* d_packed_per_dev) {
+  if (!c || !plans || n_cells < 0 || !d_coef_per_dev || !d_packed_per_dev) return fail(HOMMX_EINVAL, "hommx_solve_batch_multi_device: bad arguments");
+  if (n_cells == 0) return HOMMX_OK;
+  if (int rc = check_plans(c, plans)) return rc;
+  const int P = c->ndev;
+  const int t = hommx_plan_tensor_size(plans[0]), tt = t * t;
+  const int64_t row = tt + 1;
+  int64_t per = 0;
+  hommx_shard_range(n_cells, P, 0, nullptr, nullptr, &per);
+  for (int i = 0; i < P; ++i) {
+    int64_t b, e;
+    hommx_shard_range(n_cells, P, i, &b, &e, nullptr);
+    const int64_t nloc = e - b;
+    if (nloc > 0 && !d_coef_per_dev[i]) return fail(HOMMX_EINVAL, "null coefficient shard for device slot %d", i);
+    if (!d_packed_per_dev[i]) return fail(HOMMX_EINVAL, "null output buffer for device slot %d", i);
+    int rc = HOMMX_OK;
+    do {
+      if (hipSetDevice(c->devs[i]) != hipSuccess) { rc = fail(HOMMX_EHIP, "hipSetDevice(%d) failed", c->devs[i]); break; }
+      if ((rc = ensure_field(c, i, per * tt)) != HOMMX_OK) break;   // A_eff of the shard before packing
+      if (per > c->cap_info[i]) {
+        if (c->d_info[i]) hipFree(c->d_info[i]);
+        c->d_info[i] = nullptr;
+        c->cap_info[i] = 0;
+        if (hipMalloc(&c->d_info[i], sizeof(int32_t) * per) != hipSuccess) { rc = fail(HOMMX_ENOMEM, "info scratch on device %d", c->devs[i]); break; }
+        c->cap_info[i] = per;
+      }
+      double* slot = d_packed_per_dev[i] + (int64_t)i * per * row;
+      if (hipMemsetAsync(slot, 0, sizeof(double) * per * row, c->streams[i]) != hipSuccess) { rc = fail(HOMMX_EHIP, "memset failed"); break; }
+      if (nloc > 0) {
+        rc = hommx_solve_batch_device(plans[i], nloc, d_coef_per_dev[i], d_M_per_dev ? d_M_per_dev[i] : nullptr, c->d_field[i], c->d_info[i],
+                                      c->streams[i]);
+        if (rc != HOMMX_OK) break;
+        const long long work = nloc * row;
+        hipLaunchKernelGGL(k_pack_field, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->streams[i], c->d_field[i], c->d_info[i], slot,
+                           tt, (long long)nloc);
+        if (hipGetLastError() != hipSuccess) { rc = fail(HOMMX_EHIP, "pack kernel launch failed"); break; }
+      }
+    } while (0);
+    if (rc != HOMMX_OK) {
+      drain(c, i);
+      return rc;
+    }
+  }
+  return hommx_allgather_field(c, d_packed_per_dev, per * row);
+}
+
 int hommx_solve_batch_multi(hommx_comm* c, hommx_plan* const* plans, int64_t n_cells, const double* coef, const double* M,
                             double* A_eff, int32_t* info) {
   if (!c || !plans || n_cells < 0) return fail(HOMMX_EINVAL, "hommx_solve_batch_multi: bad arguments");
   if (n_cells == 0) return HOMMX_OK;
   if (!coef || !A_eff) return fail(HOMMX_EINVAL, "null coef / A_eff");
+  if (int rc = check_plans(c, plans)) return rc;
   const int P = c->ndev;
-  for (int i = 0; i < P; ++i)
-    if (!plans[i]) return fail(HOMMX_EINVAL, "null plan for device slot %d", i);
   const int t = hommx_plan_tensor_size(plans[0]);
   const int64_t per_coef = hommx_plan_num_elements(plans[0]) * hommx_plan_coef_components(plans[0]);
   const int tt = t * t;
   const int d = hommx_plan_dim(plans[0]);
-  const int64_t per = (n_cells + P - 1) / P;  // contiguous block partition padded to equal counts
+  int64_t per = 0;
+  hommx_shard_range(n_cells, P, 0, nullptr, nullptr, &per);
   const int64_t row = tt + 1;
-  // stage 1: every device gets ITS shard only, solves it, packs [A | info] at its slot of the gather buffer
+  // every device gets ITS shard only (H2D on its own stream), then the device-pointer form solves, packs and gathers
+  std::vector<const double*> coefs(P, nullptr), Ms(P, nullptr);
+  std::vector<double*> packed(P, nullptr);
   for (int i = 0; i < P; ++i) {
-    const int64_t b = std::min<int64_t>(n_cells, i * per), e = std::min<int64_t>(n_cells, (i + 1) * per), nloc = e - b;
-    HIP_TRY(hipSetDevice(c->devs[i]));
-    if (per > c->cap_cells[i]) {
-      if (c->d_coef[i]) hipFree(c->d_coef[i]);
-      if (c->d_M[i]) hipFree(c->d_M[i]);
-      if (c->d_info[i]) hipFree(c->d_info[i]);
-      c->d_coef[i] = c->d_M[i] = nullptr;
-      c->d_info[i] = nullptr;
-      c->cap_cells[i] = 0;
-      HIP_TRY(hipMalloc(&c->d_coef[i], sizeof(double) * per * per_coef));
-      HIP_TRY(hipMalloc(&c->d_M[i], sizeof(double) * per * d * d));
-      HIP_TRY(hipMalloc(&c->d_info[i], sizeof(int32_t) * per));
-      c->cap_cells[i] = per;
+    int64_t b, e;
+    hommx_shard_range(n_cells, P, i, &b, &e, nullptr);
+    const int64_t nloc = e - b;
+    int rc = HOMMX_OK;
+    do {
+      if (hipSetDevice(c->devs[i]) != hipSuccess) { rc = fail(HOMMX_EHIP, "hipSetDevice(%d) failed", c->devs[i]); break; }
+      if (per > c->cap_cells[i]) {
+        if (c->d_coef[i]) hipFree(c->d_coef[i]);
+        if (c->d_M[i]) hipFree(c->d_M[i]);
+        if (c->d_packed[i]) hipFree(c->d_packed[i]);
+        c->d_coef[i] = c->d_M[i] = c->d_packed[i] = nullptr;
+        c->cap_cells[i] = 0;
+        if (hipMalloc(&c->d_coef[i], sizeof(double) * per * per_coef) != hipSuccess || hipMalloc(&c->d_M[i], sizeof(double) * per * d * d) != hipSuccess ||
+            hipMalloc(&c->d_packed[i], sizeof(double) * P * per * row) != hipSuccess) {
+          rc = fail(HOMMX_ENOMEM, "staging buffers on device %d", c->devs[i]);
+          break;
+        }
+        c->cap_cells[i] = per;
+      }
+      if (nloc > 0) {
+        if (hipMemcpyAsync(c->d_coef[i], coef + b * per_coef, sizeof(double) * nloc * per_coef, hipMemcpyHostToDevice, c->streams[i]) != hipSuccess ||
+            (M && hipMemcpyAsync(c->d_M[i], M + b * d * d, sizeof(double) * nloc * d * d, hipMemcpyHostToDevice, c->streams[i]) != hipSuccess)) {
+          rc = fail(HOMMX_EHIP, "H2D copy to device %d failed", c->devs[i]);
+          break;
+        }
+      }
+    } while (0);
+    if (rc != HOMMX_OK) {
+      drain(c, i);
+      return rc;
     }
-    const int64_t need = (int64_t)P * per * row + per * tt;
-    if (need > c->cap_field[i]) {
-      if (c->d_field[i]) hipFree(c->d_field[i]);
-      c->d_field[i] = nullptr;
-      c->cap_field[i] = 0;
-      HIP_TRY(hipMalloc(&c->d_field[i], sizeof(double) * need));
-      c->cap_field[i] = need;
-    }
-    double* gather = c->d_field[i];
-    double* d_A = gather + (int64_t)P * per * row;  // per * tt doubles behind the gather buffer
-    HIP_TRY(hipMemsetAsync(gather + (int64_t)i * per * row, 0, sizeof(double) * per * row, c->streams[i]));
-    if (nloc > 0) {
-      HIP_TRY(hipMemcpyAsync(c->d_coef[i], coef + b * per_coef, sizeof(double) * nloc * per_coef, hipMemcpyHostToDevice, c->streams[i]));
-      if (M) HIP_TRY(hipMemcpyAsync(c->d_M[i], M + b * d * d, sizeof(double) * nloc * d * d, hipMemcpyHostToDevice, c->streams[i]));
-      int rc = hommx_solve_batch_device(plans[i], nloc, c->d_coef[i], M ? c->d_M[i] : nullptr, d_A, c->d_info[i], c->streams[i]);
-      if (rc != HOMMX_OK) return rc;
-      const long long work = nloc * row;
-      hipLaunchKernelGGL(k_pack_field, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->streams[i], d_A, c->d_info[i],
-                         gather + (int64_t)i * per * row, tt, (long long)nloc);
-      HIP_TRY(hipGetLastError());
-    }
+    coefs[i] = c->d_coef[i];
+    Ms[i] = M ? c->d_M[i] : nullptr;
+    packed[i] = c->d_packed[i];
   }
-  // stage 2: one all-gather of the packed field over RCCL (in place), then one D2H from the first device
-  if (int rc = hommx_allgather_field(c, c->d_field.data(), per * row)) return rc;
+  if (int rc = hommx_solve_batch_multi_device(c, plans, n_cells, coefs.data(), M ? Ms.data() : nullptr, packed.data())) return rc;
   std::vector<double> host((size_t)P * per * row);
   HIP_TRY(hipSetDevice(c->devs[0]));
-  HIP_TRY(hipMemcpy(host.data(), c->d_field[0], sizeof(double) * host.size(), hipMemcpyDeviceToHost));
-  for (int i = 0; i < P; ++i) {
-    const int64_t b = std::min<int64_t>(n_cells, i * per), e = std::min<int64_t>(n_cells, (i + 1) * per);
-    for (int64_t k = b; k < e; ++k) {
-      const double* src = host.data() + ((int64_t)i * per + (k - b)) * row;
-      std::memcpy(A_eff + k * tt, src, sizeof(double) * tt);
-      if (info) info[k] = (int32_t)src[tt];
-    }
-  }
-  return HOMMX_OK;
+  HIP_TRY(hipMemcpy(host.data(), c->d_packed[0], sizeof(double) * host.size(), hipMemcpyDeviceToHost));
+  return hommx_unpack_field(n_cells, P, tt, host.data(), A_eff, info);
 }
 
 }  // extern "C"

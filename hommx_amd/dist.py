@@ -26,20 +26,26 @@ def shard_range(n_cells: int, rank: int, world: int) -> tuple[int, int, int]:
     return b, e, per
 
 
-def default_device() -> int:
-    """Device ordinal a rank should use when the caller did not choose one: LOCAL_RANK under torchrun, else the
-    current torch device when a process group with more than one rank exists, else 0."""
+def default_device(device_count=None) -> int:
+    """Device ordinal a rank should use when the caller did not choose one.  Resolved LAZILY, at the first solve (a solver may be
+    built before ``init_process_group`` / ``torch.cuda.set_device``):  the torch device the caller has already selected
+    (``torch.cuda.current_device()`` when it is not the untouched default 0), else ``LOCAL_RANK % visible devices`` (a launcher
+    that exposes one device per rank through HIP_VISIBLE_DEVICES leaves exactly one visible ordinal, 0), else 0."""
     import os
     import sys
 
-    dist = sys.modules.get("torch.distributed")
-    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if "LOCAL_RANK" in os.environ:
-            return int(os.environ["LOCAL_RANK"])
-        import torch
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        cur = int(torch.cuda.current_device())
+        if cur != 0:
+            return cur
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None:
+        if device_count is None:
+            from . import _lib
 
-        if torch.cuda.is_available():
-            return int(torch.cuda.current_device())
+            device_count = _lib.load().hommx_device_count()
+        return int(lr) % max(1, int(device_count))
     return 0
 
 
@@ -57,6 +63,13 @@ def all_gather_field(local, n_cells: int, group=None):
     full = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(full, local.contiguous(), group=group)
     return full[:n_cells]
+
+
+FAILED = -777.0  # failure flag of a rank in the packed buffer (its own row: never confused with a cell's info)
+
+
+class ShardFailure(RuntimeError):
+    """Raised on the ranks whose own block was fine when another rank's ``local_solve`` raised."""
 
 
 def _unpad_index(n_cells: int, per: int, world: int) -> np.ndarray:
@@ -79,21 +92,37 @@ def run_sharded(t: int, n_cells: int, local_solve, group=None, device=None):
     b, e, per = shard_range(n_cells, rank, world)
     nloc = e - b
     A = info = None
+    failure = None
     if nloc > 0:
-        A, info = local_solve(b, e)
+        try:
+            A, info = local_solve(b, e)
+        except Exception as exc:  # this rank still takes part in the collective; every rank raises after it (below)
+            failure = exc
+            A = info = None
     on_gpu = torch.is_tensor(A) and A.is_cuda
     if device is None:
         if on_gpu:
             device = A.device
         elif dist.get_backend(group) == "nccl":  # RCCL moves device memory only
             device = torch.device("cuda", default_device())
-    buf = torch.zeros((per, t * t + 1), dtype=torch.float64, device=device if device is not None else "cpu")
-    if nloc > 0:
+    elif not isinstance(device, torch.device):
+        device = torch.device("cuda", int(device)) if dist.get_backend(group) == "nccl" else None
+    # one extra row per rank carries the failure flag, so that ranks agree on an exception instead of waiting for ever
+    buf = torch.zeros((per + 1, t * t + 1), dtype=torch.float64, device=device if device is not None else "cpu")
+    if failure is not None:
+        buf[per, t * t] = FAILED
+    elif nloc > 0:
         At = A if torch.is_tensor(A) else torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64))
         it = info if torch.is_tensor(info) else torch.from_numpy(np.ascontiguousarray(info))
         buf[:nloc, : t * t] = At.reshape(nloc, t * t).to(buf.device)
         buf[:nloc, t * t] = it.to(buf.device, dtype=torch.float64)
-    full = all_gather_field(buf, world * per, group).cpu().numpy()[_unpad_index(n_cells, per, world)]
+    full = all_gather_field(buf, world * (per + 1), group).cpu().numpy().reshape(world, per + 1, t * t + 1)
+    failed = [r for r in range(world) if full[r, per, t * t] == FAILED]
+    if failed:
+        if failure is not None:
+            raise failure
+        raise ShardFailure(f"micro-cell solve failed on rank(s) {failed} (see their exceptions); no field was assembled")
+    full = full[:, :per].reshape(world * per, t * t + 1)[_unpad_index(n_cells, per, world)]
     return full[:, : t * t].reshape(n_cells, t, t).copy(), np.rint(full[:, t * t]).astype(np.int32)
 
 
@@ -101,13 +130,18 @@ def _has_device_entry(plan) -> bool:
     return hasattr(plan, "solve_device") and hasattr(plan, "device")
 
 
-def solve_block(plan, coef: np.ndarray, M: np.ndarray | None):
+def _on_rccl(group=None) -> bool:
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+
+def solve_block(plan, coef: np.ndarray, M: np.ndarray | None, group=None):
     """One rank's block through ``plan``: on a real plan under the RCCL backend the result stays on the device
     (torch tensors, torch's current stream); otherwise ``plan.solve`` on host arrays."""
     import torch
-    import torch.distributed as dist
 
-    if _has_device_entry(plan) and dist.is_initialized() and dist.get_backend() == "nccl":
+    if _has_device_entry(plan) and _on_rccl(group):
         dev = torch.device("cuda", plan.device)
         nc = coef.shape[0]
         c = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(dev)
@@ -122,11 +156,32 @@ def solve_block(plan, coef: np.ndarray, M: np.ndarray | None):
     return A, (np.zeros(len(coef), np.int32) if info is None else info)
 
 
-def solve_block_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None):
+def solve_block_separable(plan, family: str, table: np.ndarray, weights: np.ndarray | None, params: np.ndarray,
+                          M: np.ndarray | None, group=None):
+    """Separable coefficient (table of g once + (a, b) per cell): under RCCL the shard's tensors stay on the device."""
     import torch
-    import torch.distributed as dist
 
-    if hasattr(plan, "solve_two_phase_device") and hasattr(plan, "device") and dist.is_initialized() and dist.get_backend() == "nccl":
+    if hasattr(plan, "solve_separable_device") and hasattr(plan, "device") and _on_rccl(group):
+        dev = torch.device("cuda", plan.device)
+        nc = params.shape[0]
+        tb = torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(dev)
+        nq = 1 if family == "affine" else int(table.shape[1])
+        w = None if weights is None else torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float64)).to(dev)
+        pr = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float64)).to(dev)
+        m = None if M is None else torch.from_numpy(np.ascontiguousarray(M, dtype=np.float64)).to(dev)
+        out = torch.empty((nc, plan.t, plan.t), dtype=torch.float64, device=dev)
+        info = torch.zeros(nc, dtype=torch.int32, device=dev)
+        plan.solve_separable_device(nc, family, nq, tb.data_ptr(), None if w is None else w.data_ptr(), pr.data_ptr(),
+                                    None if m is None else m.data_ptr(), out.data_ptr(), info.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream)
+        return out, info
+    return plan.solve_separable(family, table, weights, params, M, return_info=True)
+
+
+def solve_block_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.ndarray | None, group=None):
+    import torch
+
+    if hasattr(plan, "solve_two_phase_device") and hasattr(plan, "device") and _on_rccl(group):
         dev = torch.device("cuda", plan.device)
         nc = values.shape[0]
         mk = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8))).to(dev)
@@ -159,8 +214,8 @@ def solve_sharded(plan, coef: np.ndarray, M: np.ndarray | None, group=None, devi
 
     if not (dist.is_available() and dist.is_initialized()):
         return plan.solve(coef, M, return_info=True) if return_info else plan.solve(coef, M)
-    A, info = run_sharded(plan.t, coef.shape[0], lambda b, e: solve_block(plan, coef[b:e], None if M is None else M[b:e]),
-                          group, device)
+    A, info = run_sharded(plan.t, coef.shape[0], lambda b, e: solve_block(plan, coef[b:e], None if M is None else M[b:e], group),
+                          group, device if device is not None else getattr(plan, "device", None))
     return (A, info) if return_info else A
 
 
@@ -172,5 +227,6 @@ def solve_sharded_two_phase(plan, mask: np.ndarray, values: np.ndarray, M: np.nd
     if not (dist.is_available() and dist.is_initialized()):
         return plan.solve_two_phase(mask, values, M, return_info=True) if return_info else plan.solve_two_phase(mask, values, M)
     A, info = run_sharded(plan.t, values.shape[0],
-                          lambda b, e: solve_block_two_phase(plan, mask, values[b:e], None if M is None else M[b:e]), group, device)
+                          lambda b, e: solve_block_two_phase(plan, mask, values[b:e], None if M is None else M[b:e], group), group,
+                          device if device is not None else getattr(plan, "device", None))
     return (A, info) if return_info else A

@@ -43,8 +43,10 @@ def _unroll_dofs(dofs: np.ndarray, bs: int) -> np.ndarray:
 
 
 def micro_quadrature(dim: int, degree: int):
-    """Barycentric points / weights of the rule UFL+Basix would pick for the coefficient:
-    degree <= 1 centroid; 2: 3 / 4 points; 3: 6-point Strang-Fix (triangle), 5-point Keast (tetrahedron)."""
+    """Barycentric points / weights of the rule that samples the coefficient: degree <= 1 centroid; 2: 3 / 4
+    points; 3: 6-point Strang-Fix (triangle), 8-point collapsed Gauss-Jacobi (tetrahedron: positive weights -- the classical
+    5-point Keast rule has a weight of -0.8 and can turn the element mean of a high-contrast coefficient non-positive; Basix's
+    own 6-point Xiao-Gimbutas rule is not available offline: parity unpinned for that rule)."""
     import itertools
 
     if degree <= 1:
@@ -61,12 +63,6 @@ def micro_quadrature(dim: int, degree: int):
         p = np.full((4, 4), b)
         np.fill_diagonal(p, a)
         return p, np.full(4, 0.25)
-    if dim == 3 and degree == 3:
-        p = np.full((5, 4), 1.0 / 6.0)
-        p[0] = 0.25
-        for i in range(4):
-            p[i + 1, i] = 0.5
-        return p, np.array([-0.8, 0.45, 0.45, 0.45, 0.45])
     return fem.simplex_quadrature(dim, degree)
 
 
@@ -135,10 +131,12 @@ class Separable:
     ``A(x, y)``.  ``host_stream`` is the documented host equivalent of the device sampler: the same IEEE operations in the same
     order, hence the same bits (tests/test_gpu_separable.py)."""
 
-    def __init__(self, family: str, a, b, g):
+    def __init__(self, family: str, a, b, g, degree: int = 3):
+        """``degree``: quadrature degree of the rule that samples g -- 3 is UFL's estimate for ONE transcendental function of
+        the fast variable (sin 2 pi y0: 1 + 2), the shape of every smooth coefficient in the reference's tests."""
         if family not in ("affine", "reciprocal"):
             raise ValueError("family must be 'affine' or 'reciprocal'")
-        self.family, self.a, self.b, self.g = family, a, b, g
+        self.family, self.a, self.b, self.g, self.degree = family, a, b, g, int(degree)
 
     def params(self, c: np.ndarray) -> np.ndarray:
         """[N_c, 2] = (a, b) at the macro cell midpoints c[N_c, 3]."""
@@ -203,9 +201,13 @@ class BaseHMM(ABC):
         from the expression (hmm.py:190-198 + fem.form at :644-647): 0 for a ``conditional`` between constants, 3 for one
         transcendental function of the fast variable -- ``sin(2 pi y0)``, ``1/(2 + cos(2 pi y0))``: the coefficients of its own
         tests (test_integration_poisson.py:124-125, 149-150, 197).  A Python callable has no expression tree, so the default
-        ``None`` decides by looking at the samples: piecewise constant on every micro element -> centroid rule (degree 0),
-        anything else -> degree 3.  Pass an integer to choose the rule yourself (polynomial coefficients of another degree).
-        ``device``: HIP device ordinal; default LOCAL_RANK under an initialised torch.distributed group, else 0."""
+        ``None`` is a HEURISTIC, not UFL's estimate (a product of two transcendental factors would be 6 there, a polynomial its own
+        degree): it looks at the samples of the first, the middle and the last macro cell -- piecewise constant on every micro
+        element, or only a handful of distinct values over the cell -> centroid rule (degree 0), anything else -> degree 3 --
+        logs the choice with its evidence at WARNING level and raises when the three cells disagree.  Pass an integer to choose
+        the rule yourself; ``TwoPhase`` / ``Separable`` coefficients carry their own degree and never guess.
+        ``device``: HIP device ordinal; resolved at the first solve (``dist.default_device``: the torch device the caller selected,
+        else LOCAL_RANK modulo the visible devices, else 0)."""
         self._logger = logging.getLogger(__name__)
         self._msh = msh
         self._comm = msh.comm
@@ -231,12 +233,10 @@ class BaseHMM(ABC):
                              f"quadrature_degree={quadrature_degree} would be ignored by the device sampler")
         self._quadrature_degree = quadrature_degree  # None: decided from the samples on first use (quadrature_degree_used)
         self.quadrature_degree_used: int | None = 0 if isinstance(A, TwoPhase) else quadrature_degree
+        if isinstance(A, Separable) and quadrature_degree is None:
+            self.quadrature_degree_used = A.degree
         self._rhs_degree = rhs_quadrature_degree
-        if device is None:
-            from .dist import default_device
-
-            device = default_device()
-        self._device = device
+        self._device = device  # None: resolved lazily in _ensure_plan (the solver may be built before init_process_group)
 
         self._V_macro = self._setup_macro_function_space()
         self._macro_coordinates = self._V_macro.tabulate_dof_coordinates()
@@ -288,11 +288,8 @@ class BaseHMM(ABC):
             v = np.broadcast_to(v, (yq.shape[1],) + v.shape).copy()
         return v
 
-    def _auto_quadrature_degree(self, c_T: np.ndarray) -> int:
-        """Default policy (see __init__): sample A(c_T, .) at the degree-3 points of every micro element.  A ``conditional``
-        between constants (UFL: degree 0, centroid rule) shows up as a coefficient that is constant on every element or -- when
-        its interface cuts through elements, like the wrapped disc of inclusion.py:107-118 -- takes only a handful of distinct
-        values over the whole cell; anything else is treated as smooth: degree 3."""
+    def _quadrature_evidence(self, c_T: np.ndarray) -> tuple[int, str]:
+        """Degree the heuristic picks from the samples of ONE macro cell, and why."""
         d = self._tdim
         bary, _ = micro_quadrature(d, 3)
         Xe = self._cell_mesh.cell_vertices()
@@ -300,14 +297,37 @@ class BaseHMM(ABC):
         v = self._sample_one(c_T, yq.reshape(-1, d).T)
         v = v.reshape((yq.shape[0], yq.shape[1]) + v.shape[1:])
         if np.all(v == v[:, :1]):
-            return 0
+            return 0, "constant on every micro element"
         flat = v.reshape(v.shape[0] * v.shape[1], -1)
-        return 0 if all(np.unique(flat[:, k]).size <= 8 for k in range(flat.shape[1])) else 3
+        distinct = max(int(np.unique(flat[:, k]).size) for k in range(flat.shape[1]))
+        if distinct <= 8:
+            return 0, f"{distinct} distinct values over the cell (a conditional whose interface cuts elements)"
+        return 3, f"{distinct} distinct values over the cell, varying inside elements (smooth in y)"
+
+    def _auto_quadrature_degree(self, c_T: np.ndarray | None = None) -> int:
+        """Default policy (see __init__): sample A(c_T, .) at the degree-3 points of every micro element of the first, the middle
+        and the last macro cell.  A ``conditional`` between constants (UFL: degree 0, centroid rule) shows up as a coefficient
+        that is constant on every element or -- when its interface cuts through elements, like the wrapped disc of
+        inclusion.py:107-118 -- takes only a handful of distinct values over the whole cell; anything else is treated as smooth:
+        degree 3.  The choice is logged with its evidence; cells that disagree raise (a wrong guess would silently solve a
+        different discrete problem from the reference's)."""
+        mid = self._msh.cell_midpoints()
+        probe = [0, len(mid) // 2, len(mid) - 1] if c_T is None else [None]
+        found = [self._quadrature_evidence(mid[k] if k is not None else c_T) for k in probe]
+        degrees = sorted({f[0] for f in found})
+        if len(degrees) > 1:
+            raise ValueError("cannot guess the micro quadrature degree of A(x, y): macro cells " + ", ".join(
+                f"{k}: degree {f[0]} ({f[1]})" for k, f in zip(probe, found)) + " -- pass quadrature_degree= explicitly "
+                "(0 for a conditional between constants, 3 for one transcendental function of y: what UFL estimates, hmm.py:190-198)")
+        self._logger.warning("quadrature_degree not given: guessed degree %d for A(x, y) from its samples (%s); pass "
+                             "quadrature_degree= to choose the rule UFL would estimate for your expression",
+                             degrees[0], "; ".join(f"cell {k}: {f[1]}" for k, f in zip(probe, found)))
+        return degrees[0]
 
     def _element_means(self, cells: np.ndarray) -> tuple[np.ndarray, str]:
         d = self._tdim
         if self.quadrature_degree_used is None:
-            self.quadrature_degree_used = self._auto_quadrature_degree(self._msh.cell_midpoints()[0])
+            self.quadrature_degree_used = self._auto_quadrature_degree()
         bary, w = micro_quadrature(d, self.quadrature_degree_used)
         Xe = self._cell_mesh.cell_vertices()  # [n_el, d+1, d]
         yq = np.einsum("qa,eak->eqk", bary, Xe)
@@ -386,16 +406,40 @@ class BaseHMM(ABC):
         raise ValueError("elasticity coefficient must be Lame(lam, mu) or a [d,d,d,d] tensor")
 
     def _stratification(self, cells: np.ndarray) -> np.ndarray | None:
+        """M[c] = Dtheta_transpose(c_T) of the given macro cells (hmm.py:756-757, 1015-1016).  ONE broadcast call
+        ``Dtheta_transpose(x[3, N_c]) -> [d, d, N_c]`` when the callable allows it (accepted only if it reproduces the per-cell
+        call on the first and the last cell), else one call per cell as the reference does."""
         if self._Dtheta_t is None:
             return None
         c = self._msh.cell_midpoints()[cells]
         d = self._tdim
-        M = np.empty((len(cells), d, d))
-        for k in range(len(cells)):
-            m = np.asarray(self._Dtheta_t(c[k]), dtype=float)
+        nc = len(cells)
+
+        def one(x):
+            m = np.asarray(self._Dtheta_t(x), dtype=float)
             if m.shape != (d, d):
                 raise ValueError(f"Dtheta_transpose must return a {d}x{d} matrix (hmm.py:741, :762); got {m.shape}")
-            M[k] = m
+            return m
+
+        if nc == 0:
+            return np.empty((0, d, d))
+        first, last = one(c[0]), one(c[-1])
+        if nc >= 4:
+            try:
+                rows = self._Dtheta_t(c.T)
+                mb = np.empty((d, d, nc))
+                for i in range(d):
+                    for j in range(d):
+                        mb[i, j] = np.broadcast_to(np.asarray(rows[i][j], dtype=float), (nc,))
+                mb = np.ascontiguousarray(np.moveaxis(mb, -1, 0))
+                if np.array_equal(mb[0], first) and np.array_equal(mb[-1], last):
+                    return mb
+            except Exception:
+                pass
+        M = np.empty((nc, d, d))
+        M[0], M[-1] = first, last
+        for k in range(1, nc - 1):
+            M[k] = one(c[k])
         return M
 
     # -- the hot path (replaces the loop hmm.py:298-332) ---------------------------------------------
@@ -409,8 +453,16 @@ class BaseHMM(ABC):
 
     def _ensure_plan(self, kind: str) -> MicroCellPlan:
         if self._plan is None or self._plan.kind != kind:
+            if self._device is None:
+                from .dist import default_device
+
+                self._device = default_device()
             self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
         return self._plan
+
+    def _shard_device(self):
+        """Device of the gather buffer under RCCL = the plan's device (None before a plan exists on a gloo / stub-plan run)."""
+        return getattr(self._plan, "device", None) if self._plan is not None else self._device
 
     def _tensor_size(self) -> int:
         d = self._tdim
@@ -436,7 +488,7 @@ class BaseHMM(ABC):
                 coef, kind = self._element_means(sub)
                 return solve_block(self._ensure_plan(kind), coef, self._stratification(sub))
 
-            return run_sharded(self._tensor_size(), len(cells), local)
+            return run_sharded(self._tensor_size(), len(cells), local, device=self._shard_device())
         coef, kind = self._element_means(cells)
         M = self._stratification(cells)
         return self._ensure_plan(kind).solve(coef, M, return_info=True)
@@ -447,22 +499,21 @@ class BaseHMM(ABC):
         if not hasattr(plan, "solve_separable"):
             return None
         d = self._tdim
-        if self.quadrature_degree_used is None:
-            self.quadrature_degree_used = self._auto_quadrature_degree(self._msh.cell_midpoints()[0])
+        if self.quadrature_degree_used is None:  # not reached for Separable (it carries its degree); kept for subclasses
+            self.quadrature_degree_used = self._auto_quadrature_degree()
         bary, w = micro_quadrature(d, self.quadrature_degree_used)
         yq = np.einsum("qa,eak->eqk", bary, self._cell_mesh.cell_vertices())
         co = self._coeff
         table = co.table(yq, w)
 
-        def local(sub):
-            return plan.solve_separable(co.family, table, w, co.params(self._msh.cell_midpoints()[sub]), self._stratification(sub),
-                                        return_info=True)
-
         if self._sharded():
-            from .dist import run_sharded
+            from .dist import run_sharded, solve_block_separable
 
-            return run_sharded(self._tensor_size(), len(cells), lambda b, e: local(cells[b:e]))
-        return local(cells)
+            return run_sharded(self._tensor_size(), len(cells),
+                               lambda b, e: solve_block_separable(plan, co.family, table, w, co.params(self._msh.cell_midpoints()[cells[b:e]]),
+                                                                  self._stratification(cells[b:e])), device=self._shard_device())
+        return plan.solve_separable(co.family, table, w, co.params(self._msh.cell_midpoints()[cells]), self._stratification(cells),
+                                    return_info=True)
 
     def _effective_tensors_two_phase(self, cells: np.ndarray):
         """Device-side sampling of a ``TwoPhase`` coefficient: one mask + two values per macro cell."""
@@ -484,7 +535,8 @@ class BaseHMM(ABC):
             from .dist import run_sharded, solve_block_two_phase
 
             return run_sharded(self._tensor_size(), len(cells),
-                               lambda b, e: solve_block_two_phase(plan, mask, values_of(cells[b:e]), self._stratification(cells[b:e])))
+                               lambda b, e: solve_block_two_phase(plan, mask, values_of(cells[b:e]), self._stratification(cells[b:e])),
+                               device=self._shard_device())
         return plan.solve_two_phase(mask, values_of(cells), self._stratification(cells), return_info=True)
 
     def _local_stiffness_from_tensors(self, cells: np.ndarray, AH: np.ndarray) -> np.ndarray:
@@ -526,9 +578,7 @@ class BaseHMM(ABC):
         cells = np.array([cell_index])
         coef, kind = self._element_means(cells)
         M = self._stratification(cells)
-        if self._plan is None or self._plan.kind != kind:
-            self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
-        _, chi = self._plan.solve(coef, M, return_correctors=True)  # [1, t, n^d * bs]
+        _, chi = self._ensure_plan(kind).solve(coef, M, return_correctors=True)  # [1, t, n^d * bs]
         d, bs = self._tdim, self._bs
         X = self._msh.cell_vertices()[cells][0]
         G = np.linalg.inv(np.concatenate([np.ones((d + 1, 1)), X], axis=1))[1:, :].T  # grad phi_a
@@ -696,9 +746,7 @@ class PoissonPeriodicHMM:
         h = self._inner
         cells = np.array([0])
         coef, kind = h._element_means(cells)
-        if h._plan is None or h._plan.kind != kind:
-            h._plan = MicroCellPlan(h._tdim, h._n_micro, kind, device=h._device)
-        AH, chi, info = h._plan.solve(coef, None, return_info=True, return_correctors=True)
+        AH, chi, info = h._ensure_plan(kind).solve(coef, None, return_info=True, return_correctors=True)
         if info[0]:
             h._logger.error("Something went wrong in the cell problem solving for the periodic cell")
         self._A_hom = AH[0]

@@ -75,9 +75,14 @@ int hommx_plan_create(hommx_plan** out, const hommx_plan_desc* desc);
 int hommx_plan_destroy(hommx_plan* plan);
 
 /* Shape queries: elements per micro mesh (2 n^2 / 6 n^3), coefficient doubles per element,
- * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), and the name of the
- * kernel family the plan dispatches to ("fused2d" / "blocked"). */
+ * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), the descriptor fields, and the name of the
+ * kernel route the plan's effective-tensor solves take: "fused2d" (2D scalar Poisson, n <= 32), "small_wave" (plane block
+ * b <= 48: one wavefront per cell), "small_fused" (48 < b <= 64: LDS), "multifrontal" (3D, b >= 192: nested dissection,
+ * batched fronts) or "blocked" (everything else, and the corrector entry point of every plan). */
 int32_t hommx_plan_dim(const hommx_plan* plan);
+int32_t hommx_plan_device(const hommx_plan* plan);
+int32_t hommx_plan_n_micro(const hommx_plan* plan);
+int32_t hommx_plan_kind(const hommx_plan* plan);
 int64_t hommx_plan_num_elements(const hommx_plan* plan);
 int32_t hommx_plan_coef_components(const hommx_plan* plan);
 int32_t hommx_plan_tensor_size(const hommx_plan* plan);
@@ -181,8 +186,25 @@ int hommx_allgather_field(hommx_comm* comm, double* const* d_field_per_dev, int6
 int hommx_solve_batch_multi(hommx_comm* comm, hommx_plan* const* plans, int64_t n_cells, const double* coef, const double* M,
                             double* A_eff, int32_t* info);
 
-/* Calibration micro-benchmark: sustained fp64 MFMA rate (v_mfma_f64_16x16x4_f64, all CUs), in FLOP/s.
- * Used by bench.py to state the fp64 matrix peak next to the datasheet figure. */
+/* DEVICE-pointer form: the inputs stay resident on their devices (no H2D per call).  d_coef_per_dev[i] / d_M_per_dev[i] point at
+ * the shard of device i (cells [begin_i, end_i) of hommx_shard_range, its own first cell at offset 0) on device i;
+ * d_packed_per_dev[i] is a buffer of ndev * per_dev * (t*t + 1) doubles on device i that receives the whole gathered field, one row
+ * [A_eff (t*t) | info as a double] per cell slot, shard after (padded) shard -- hommx_unpack_field() reads that layout on the host.
+ * Returns after the all-gather has completed on every device. */
+int hommx_solve_batch_multi_device(hommx_comm* comm, hommx_plan* const* plans, int64_t n_cells, const double* const* d_coef_per_dev,
+                                   const double* const* d_M_per_dev, double* const* d_packed_per_dev);
+
+/* The block partition and the layout of the gathered field as plain host arithmetic (no GPU needed): cells of device i are
+ * [begin, end) = [i * per_dev, min(n_cells, (i+1) * per_dev)), per_dev = ceil(n_cells / ndev)  (the reference's
+ * MPI ownership ranges, hmm.py:307-310). */
+int hommx_shard_range(int64_t n_cells, int32_t ndev, int32_t i, int64_t* begin, int64_t* end, int64_t* per_dev);
+int hommx_unpack_field(int64_t n_cells, int32_t ndev, int32_t tt, const double* packed, double* A_eff, int32_t* info);
+
+/* Calibration micro-benchmark, in FLOP/s: the best sustained rate of v_mfma_f64_16x16x4_f64 (8 independent accumulator tiles per
+ * wave) and of v_fma_f64 (16 independent accumulators per lane) over 2 and 4 waves per SIMD on all CUs.  Both instructions share one
+ * fp64 pipe on MI355X; bench.py reports the larger as the measured fp64 peak next to the datasheet figure.
+ * hommx_calibrate_fp64_mfma is the MFMA figure alone (kept for callers of the first ABI revision). */
+int hommx_calibrate_fp64(int device, double* mfma_flops_per_s, double* fma_flops_per_s);
 int hommx_calibrate_fp64_mfma(int device, double* flops_per_s);
 
 const char* hommx_last_error(void);

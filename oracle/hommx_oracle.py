@@ -125,8 +125,9 @@ def quadrature_rule(dim: int, degree: int):
 
     3P-memory: Basix default rules.  degree<=1: centroid.  degree 2: 3 / 4 interior points.
     Triangle degree 3: 6-point Strang-Fix rule.  Tetrahedron degree 3: Basix uses a 6-point
-    Xiao-Gimbutas rule whose digits are not available offline, so degree 3 in 3D uses the classical
-    5-point Keast rule (also exact to degree 3) -- parity unpinned for that case.
+    Xiao-Gimbutas rule whose digits are not available offline, so degree 3 in 3D uses the 8-point
+    collapsed Gauss-Jacobi rule (also exact to degree 3, positive weights -- the classical 5-point
+    Keast rule has a weight of -0.8) -- parity unpinned for that case.
 
     Only the element mean of A enters the discrete problem (P1 gradients are element-wise
     constant), so the rule only matters for non-piecewise-constant A.
@@ -146,13 +147,23 @@ def quadrature_rule(dim: int, degree: int):
         p = np.full((4, 4), b)
         np.fill_diagonal(p, a)
         return p, np.full(4, 0.25)
-    # Keast 5-point, degree 3
-    p = np.full((5, 4), 1.0 / 6.0)
-    p[0] = 0.25
-    for i in range(4):
-        p[i + 1, i] = 0.5
-    w = np.array([-0.8, 0.45, 0.45, 0.45, 0.45])
-    return p, w
+    return _collapsed_gauss_jacobi_tet(2)
+
+
+def _collapsed_gauss_jacobi_tet(m: int):
+    """m^3-point collapsed Gauss-Jacobi rule on the tetrahedron (exact to degree 2m - 1, positive weights): barycentric points
+    and weights summing to 1."""
+    from scipy.special import roots_jacobi, roots_legendre
+
+    x0, w0 = roots_jacobi(m, 2.0, 0.0)
+    x1, w1 = roots_jacobi(m, 1.0, 0.0)
+    x2, w2 = roots_legendre(m)
+    a = 0.5 * (x0 + 1.0)[:, None, None] * np.ones((1, m, m))
+    b = 0.5 * (x1 + 1.0)[None, :, None] * np.ones((m, 1, m))
+    c = 0.5 * (x2 + 1.0)[None, None, :] * np.ones((m, m, 1))
+    l1, l2, l3 = a, (1.0 - a) * b, (1.0 - a) * (1.0 - b) * c
+    w = (w0[:, None, None] * w1[None, :, None] * w2[None, None, :]).ravel()
+    return np.stack([1.0 - l1 - l2 - l3, l1, l2, l3], axis=-1).reshape(-1, 4), w / w.sum()
 
 
 def element_quadrature_points(dim: int, n: int, degree: int):

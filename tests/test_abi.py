@@ -89,3 +89,36 @@ def test_workloads_shapes():
     msh, coef, M = W.c5_rotated_fibres(shape=(2, 1, 1), n=4)
     assert coef.shape == (12, 384, 2) and M.shape == (12, 3, 3)
     assert np.isclose(msh.cell_volumes().sum(), 1.0 * 0.4 * 0.1)
+
+
+@pytest.mark.parametrize("n_cells,ndev", [(10, 4), (8192, 8), (7, 8), (0, 2), (24576, 3), (5, 1)])
+def test_c_abi_shard_range_and_unpack(lib, n_cells, ndev):
+    """The partition / unpack index arithmetic of hommx_solve_batch_multi as plain host functions (no GPU): P > 1, ragged shards,
+    more devices than cells.  Same bounds as hommx_amd.dist.shard_range (the reference's MPI ownership ranges, hmm.py:307-310)."""
+    from hommx_amd.dist import shard_range
+
+    i64 = ctypes.c_int64
+    cover, per0 = [], None
+    for i in range(ndev):
+        b, e, per = i64(), i64(), i64()
+        assert lib.hommx_shard_range(n_cells, ndev, i, ctypes.byref(b), ctypes.byref(e), ctypes.byref(per)) == 0
+        assert (b.value, e.value, per.value) == shard_range(n_cells, i, ndev)
+        per0 = per.value
+        cover += list(range(b.value, e.value))
+    assert cover == list(range(n_cells))
+    assert lib.hommx_shard_range(5, 2, 2, None, None, None) == -1 and lib.hommx_shard_range(5, 0, 0, None, None, None) == -1
+    if n_cells == 0:
+        return
+    tt = 4
+    # gathered layout: device i's padded shard at rows [i * per, (i + 1) * per); cell k carries (k, k + 0.25, ...) and info = k % 3
+    packed = np.full((ndev, per0, tt + 1), -5.0)
+    for i in range(ndev):
+        b, e, _ = shard_range(n_cells, i, ndev)
+        for k in range(b, e):
+            packed[i, k - b, :tt] = k + 0.25 * np.arange(tt)
+            packed[i, k - b, tt] = k % 3
+    A = np.empty((n_cells, tt))
+    info = np.empty(n_cells, np.int32)
+    assert lib.hommx_unpack_field(n_cells, ndev, tt, packed.ctypes.data, A.ctypes.data, info.ctypes.data) == 0
+    assert np.array_equal(A, np.arange(n_cells)[:, None] + 0.25 * np.arange(tt)[None, :])
+    assert np.array_equal(info, np.arange(n_cells) % 3)

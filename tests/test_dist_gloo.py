@@ -129,7 +129,7 @@ def _hmm_worker(rank, world, port, q):
         h._plan = plan
         errors = []
         handler = logging.Handler()
-        handler.emit = lambda rec, errors=errors: errors.append(rec.getMessage())
+        handler.emit = lambda rec, errors=errors: errors.append(rec.getMessage()) if rec.levelno >= logging.ERROR else None
         logging.getLogger("hommx_amd.hmm").addHandler(handler)
         u = h.solve()
         logging.getLogger("hommx_amd.hmm").removeHandler(handler)
@@ -168,3 +168,69 @@ def test_two_rank_hmm_solve_end_to_end():
         bad = got[r]["poisoned"]
         assert bad["info"][13] == 3 and bad["info"].sum() == 3   # the poisoned cell's flag survives the all-gather on both ranks
         assert any("cell 13" in m for m in bad["errors"])        # and is logged like the reference (hmm.py:320-323)
+
+
+# ---- a failing rank must not leave the others in the collective for ever --------------------------------------------------------
+def _failing_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from hommx_amd.dist import ShardFailure, run_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local(b, e):
+        if rank == 1:
+            raise ValueError("matrix-valued A must be symmetric (only this rank's shard trips the check)")
+        return np.ones((e - b, 2, 2)), np.zeros(e - b, np.int32)
+
+    try:
+        run_sharded(2, 7, local)
+        q.put((rank, "returned"))
+    except ValueError as exc:
+        q.put((rank, "own:" + str(exc)[:20]))
+    except ShardFailure as exc:
+        q.put((rank, "peer:" + str(exc)))
+    # the group is still usable afterwards: both ranks left the collective
+    A, info = run_sharded(2, 7, lambda b, e: (np.full((e - b, 2, 2), float(rank)), np.zeros(e - b, np.int32)))
+    assert A[0, 0, 0] == 0.0 and A[-1, 0, 0] == 1.0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_raises_on_all_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1].startswith("own:matrix-valued")
+    assert got[0].startswith("peer:") and "rank(s) [1]" in got[0]
+
+
+def test_default_device_is_resolved_lazily(monkeypatch):
+    """A solver built BEFORE init_process_group must not freeze device 0 on every rank: the device is chosen at the first solve
+    from LOCAL_RANK modulo the visible devices (one device per rank through HIP_VISIBLE_DEVICES -> ordinal 0)."""
+    sys.path.insert(0, ROOT)
+    from hommx_amd import hmm, mesh
+    from hommx_amd.dist import default_device
+
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert default_device(device_count=8) == 0
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert default_device(device_count=8) == 3
+    assert default_device(device_count=1) == 0   # launcher exposed ONE device to this rank
+    assert default_device(device_count=0) == 0   # no device: the plan constructor reports that, not an index error here
+    h = hmm.PoissonHMM(mesh.create_unit_square(2, 2), lambda x, y: 1.0 + 0 * y[0], lambda x: 1.0, mesh.create_unit_square(4, 4), 0.1)
+    assert h._device is None                      # nothing decided at construction time
+    h2 = hmm.PoissonHMM(mesh.create_unit_square(2, 2), lambda x, y: 1.0 + 0 * y[0], lambda x: 1.0, mesh.create_unit_square(4, 4), 0.1, device=5)
+    assert h2._device == 5                        # an explicit device always wins

@@ -50,6 +50,29 @@ def test_solve_batch_multi_one_device():
         back = np.empty(12)
         assert hip.hipMemcpy(back.ctypes.data, d, 96, 2) == 0
         assert np.array_equal(back, src)
+        # device-pointer form: the coefficient shard stays resident, the packed field [A | info] comes back gathered
+        p2 = MicroCellPlan(2, 16, "poisson")
+        coef = rng.uniform(0.3, 3.0, size=(11, p2.n_el)); coef[4] = -1.0
+        ref, ref_info = p2.solve(coef, return_info=True)
+        dc, dp = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dc), coef.nbytes) == 0 and hip.hipMalloc(ctypes.byref(dp), 11 * 5 * 8) == 0
+        assert hip.hipMemcpy(dc, coef.ctypes.data, coef.nbytes, 1) == 0
+        plans = (ctypes.c_void_p * 1)(p2._h.value)
+        coefs, packs = (ctypes.c_void_p * 1)(dc.value), (ctypes.c_void_p * 1)(dp.value)
+        _lib.check(lib.hommx_solve_batch_multi_device(h, plans, 11, coefs, None, packs), "multi_device")
+        packed = np.empty((11, 5))
+        assert hip.hipMemcpy(packed.ctypes.data, dp, packed.nbytes, 2) == 0
+        A = np.empty((11, 2, 2)); info = np.empty(11, np.int32)
+        _lib.check(lib.hommx_unpack_field(11, 1, 4, packed.ctypes.data, A.ctypes.data, info.ctypes.data), "unpack")
+        assert np.array_equal(info, ref_info) and info[4] > 0
+        ok = info == 0
+        assert np.array_equal(A[ok], ref[ok])
+        # a plan of another shape in the slot is refused, with a message
+        wrong = (ctypes.c_void_p * 1)(MicroCellPlan(2, 8, "poisson")._h.value)
+        ms2 = MultiGpuSolver(2, 16, "poisson", devices=[0])
+        assert lib.hommx_solve_batch_multi_device(ms2._h, wrong, 11, coefs, None, packs) == 0  # one plan: nothing to compare with
+        ms2.close()
+        assert lib.hommx_comm_init_all(ctypes.byref(ctypes.c_void_p()), 2, (ctypes.c_int * 2)(0, 0)) == -1  # the same device twice
         lib.hommx_comm_destroy(h)
         print("ok")
     """)
