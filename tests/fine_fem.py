@@ -112,6 +112,80 @@ def solve_fine(N: int, A_of_x, f_val: float, g_of_x, rtol: float = 1e-10):
     return u, its[0]
 
 
+def _interp_1d_full(nf: int) -> sp.csr_matrix:
+    """Linear interpolation from the nf/2 + 1 nodes of the coarse 1D grid (end nodes included: natural boundary) to the nf + 1 fine ones."""
+    rows, cols, vals = [], [], []
+    for i in range(nf + 1):
+        if i % 2 == 0:
+            rows.append(i); cols.append(i // 2); vals.append(1.0)
+        else:
+            rows += [i, i]; cols += [(i - 1) // 2, (i + 1) // 2]; vals += [0.5, 0.5]
+    return sp.csr_matrix((vals, (rows, cols)), shape=(nf + 1, nf // 2 + 1))
+
+
+def solve_fine_darcy(N: int, A_of_x, f_val: float = 1.0, diagonal: str = "right", rtol: float = 1e-11):
+    """The fine-scale reference solve of the reference's two diffusion examples (examples/diffusion/inclusion.py:140-161,
+    laminate.py:131-144): P1 on create_unit_square(N, N), -div(A grad u) = f_val, "Darcy" data u = 1 on x0 = 0, u = 0 on x0 = 1
+    (inclusion.py:64-88), natural conditions on x1 = 0, 1.  The coefficient is a ``ufl.conditional`` between constants, for which UFL
+    estimates quadrature degree 0: ONE sample per triangle, at its centroid.  ``diagonal``: "right" (DOLFINx's default: squares split
+    along v00 - v11) or "left" (v10 - v01), to see whether a reference-held number tells the two triangulations apart.
+    Returns u[(N+1), (N+1)] at the nodes (i / N, j / N) and the CG iteration count."""
+    h = 1.0 / N
+    xc, yc = np.meshgrid(np.arange(N) * h, np.arange(N) * h, indexing="ij")  # lower-left corners of the squares
+    third = h / 3.0
+    cH = np.zeros((N, N + 1))          # edge (i, j) - (i + 1, j)
+    cV = np.zeros((N + 1, N))          # edge (i, j) - (i, j + 1)
+    if diagonal == "right":            # lower triangle (v00, v10, v11): legs bottom + right; upper (v00, v01, v11): legs left + top
+        aL = A_of_x(np.stack([xc + 2 * third, yc + third]))
+        aU = A_of_x(np.stack([xc + third, yc + 2 * third]))
+        cH[:, :N] += 0.5 * aL; cH[:, 1:] += 0.5 * aU
+        cV[:N, :] += 0.5 * aU; cV[1:, :] += 0.5 * aL
+    elif diagonal == "left":           # (v00, v10, v01): legs bottom + left; (v10, v11, v01): legs right + top
+        aL = A_of_x(np.stack([xc + third, yc + third]))
+        aU = A_of_x(np.stack([xc + 2 * third, yc + 2 * third]))
+        cH[:, :N] += 0.5 * aL; cH[:, 1:] += 0.5 * aU
+        cV[:N, :] += 0.5 * aL; cV[1:, :] += 0.5 * aU
+    else:
+        raise ValueError(diagonal)
+    mx, my = N - 1, N + 1              # unknowns (i, j), 1 <= i <= N - 1, 0 <= j <= N, index (i - 1) my + j
+    cW, cE = cH[0:N - 1, :], cH[1:N, :]
+    cS = np.zeros((mx, my)); cS[:, 1:] = cV[1:N, :]
+    cNn = np.zeros((mx, my)); cNn[:, :N] = cV[1:N, :]
+    diag = (cW + cE + cS + cNn).ravel()
+    east = -cE.copy(); east[-1, :] = 0.0
+    e = east.ravel()[: mx * my - my]
+    nth = (-cNn).ravel()[: mx * my - 1]                       # zero where j = N: no coupling across rows of the index
+    K = sp.diags([diag, e, e, nth, nth], [0, my, -my, 1, -1], format="csr")
+    rhs = np.full((mx, my), f_val * h * h)
+    rhs[:, 0] *= 0.5; rhs[:, -1] *= 0.5                       # three triangles instead of six around a node of the natural boundary
+    rhs[0, :] += cW[0, :] * 1.0                               # u = 1 on x0 = 0; u = 0 on x0 = 1 adds nothing
+
+    class _MG(_Multigrid):
+        def __init__(self, K, n, coarsest=16):
+            self.levels = []
+            while True:
+                D = K.diagonal()
+                if n <= coarsest:
+                    self.levels.append((K, D, None))
+                    self.coarse = spl.splu(K.tocsc())
+                    break
+                P = sp.kron(_interp_1d(n), _interp_1d_full(n), format="csr")
+                self.levels.append((K, D, P))
+                K = (P.T @ K @ P).tocsr()
+                n //= 2
+
+    mg = _MG(K, N)
+    M = spl.LinearOperator(K.shape, matvec=mg.vcycle)
+    its = [0]
+    sol, info = spl.cg(K, rhs.ravel(), rtol=rtol, atol=0.0, M=M, maxiter=400, callback=lambda xk: its.__setitem__(0, its[0] + 1))
+    if info != 0:
+        raise RuntimeError(f"fine-scale CG did not converge (info {info})")
+    u = np.zeros((N + 1, N + 1))
+    u[0, :] = 1.0
+    u[1:N, :] = sol.reshape(mx, my)
+    return u, its[0]
+
+
 # Kuhn (Freudenthal) split of a cube into six tetrahedra around the diagonal v000 - v111, one per order in which the path from v000 to v111
 # takes its three axis steps (DOLFINx create_unit_cube).  The P1 gradients of such a tetrahedron are -e_p1, e_p1 - e_p2, e_p2 - e_p3, e_p3
 # (over h): only consecutive path vertices couple, i.e. only axis-parallel edges carry a conductance, a_tet h / 6 per path step.
