@@ -22,6 +22,7 @@
 #include <string>
 
 #include "../../include/hommx_hip.h"
+#include "blocked_internal.h"
 #include "geo.h"
 #include "kernels.h"
 #include "sweep.h"
@@ -29,7 +30,7 @@
 namespace hommx {
 
 
-static thread_local std::string g_berr;
+thread_local std::string g_berr;
 const char* blocked_last_error() { return g_berr.c_str(); }
 
 #define BTRY(expr)                                                                       \
@@ -781,7 +782,7 @@ __global__ void k_transpose(int M, int N, const double* __restrict__ IN, int ldi
 // in-place inverse of the NB x NB SPD diagonal sub-block at (off, off): one wavefront per cell
 template <int NB>
 __global__ __launch_bounds__(64) void k_leaf_inverse(double* __restrict__ S, int ld, long long stride, int off,
-                                                     int32_t* __restrict__ info, int stepcode) {
+                                                     int32_t* __restrict__ info, int stepcode, int infoDiv) {
   constexpr int RPL = Cfg<NB>::RPL;
   __shared__ alignas(16) double ubuf[NB];
   __shared__ alignas(16) double wbuf[NB];
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(64) void k_leaf_inverse(double* __restrict__ S, int
   SweepStep<NB, 0>::run(s, ubuf, wbuf, c, g, r0, bad);
 #pragma unroll
   for (int i = 0; i < RPL; ++i) P[(long long)(r0 + i) * ld + c] = -s[i];
-  if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
+  if (bad && l == 0 && info) atomicCAS(&info[cell / infoDiv], 0, stepcode);
 }
 
 // same for NB = 64 in the block layout of sweep_blk (lane = 8x8 block, 128 VGPRs of matrix): one launch instead of the
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(64) void k_leaf_inverse(double* __restrict__ S, int
 // (blocks above the diagonal are mirrored on the way in), writes the full symmetric inverse.
 template <int NB>
 __global__ __launch_bounds__(64) void k_leaf_inverse_blk(double* __restrict__ S, int ld, long long stride, int off,
-                                                         int32_t* __restrict__ info, int stepcode) {
+                                                         int32_t* __restrict__ info, int stepcode, int infoDiv) {
   constexpr int BS = NB / 8;
   __shared__ alignas(16) double ubuf[NB];
   const long long cell = blockIdx.x;
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(64) void k_leaf_inverse_blk(double* __restrict__ S,
   for (int r = 0; r < BS; ++r)
 #pragma unroll
     for (int q = 0; q < BS; ++q) P[(long long)(BS * bi + r) * ld + BS * bj + q] = -s[r * BS + q];
-  if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
+  if (bad && l == 0 && info) atomicCAS(&info[cell / infoDiv], 0, stepcode);
 }
 
 // two-phase media: expand (mask, per-cell phase values) into the element stream the assembly reads
@@ -878,25 +879,6 @@ hipError_t launch_expand_separable(CoefSource src, const double* d_params, doubl
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------
-struct BlockedWorkspace {
-  Geo G;
-  // development knobs, read ONCE when the plan is created (include/hommx_hip.h lists them)
-  double budget_gb_env = 0.0;  // HOMMX_BLOCKED_MEM_GB (0: automatic)
-  int gemm128_min = 256;       // HOMMX_GEMM128_MIN
-  bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
-  bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
-  bool split64 = true;         // HOMMX_NO_SPLIT64: halve 192 into 96 + 96 (32- and 64-leaves) instead of 64 + 128
-  bool small_fused = true;     // HOMMX_NO_SMALL_FUSED switches the LDS-resident kernel for b <= 64 off (A/B runs)
-  int small_waves = 0;         // HOMMX_SMALL_WAVES: 2 / 4 = the LDS kernel with that many waves per macro cell; 0 = default routes
-  long long chunk = 0;
-  double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
-  double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
-  double *R = nullptr, *Rl = nullptr, *Vr = nullptr, *Gm = nullptr;
-  // corrector mode: per eliminated plane the inverse Schur block, the arrow block and the load rows are kept
-  long long hchunk = 0;
-  double *hS = nullptr, *hW = nullptr, *hR = nullptr, *Xa = nullptr, *Xb = nullptr, *Y = nullptr;
-};
-
 static void fill_tables(Geo& G) {
   static const int tri[2][3][2] = {{{0, 0}, {1, 0}, {1, 1}}, {{0, 0}, {0, 1}, {1, 1}}};
   static const int vb[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
@@ -966,6 +948,13 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   ws->split64 = getenv("HOMMX_NO_SPLIT64") == nullptr;
   ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
   if (const char* e = getenv("HOMMX_SMALL_WAVES")) ws->small_waves = atoi(e);
+  if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
+  if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && G.b > 64) {
+    if (int rc = mf_plan_create(&ws->mf, G)) {
+      delete ws;
+      return rc;
+    }
+  }
   *out = ws;
   return 0;
 }
@@ -973,7 +962,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
 const char* blocked_route_name(const BlockedWorkspace* ws) {
   if (!ws) return "blocked";
   if (ws->G.b <= 64 && ws->small_fused) return (ws->G.b <= 48 && ws->small_waves != 2 && ws->small_waves != 4) ? "small_wave" : "small_fused";
-  return "blocked";
+  return ws->mf ? "multifrontal" : "blocked";
 }
 
 static void ws_free_main(BlockedWorkspace* ws) {
@@ -1001,6 +990,7 @@ static void ws_free(BlockedWorkspace* ws) {
 
 void blocked_workspace_destroy(BlockedWorkspace* ws) {
   if (!ws) return;
+  if (ws->mf) mf_plan_destroy(ws->mf);
   ws_free(ws);
   delete ws;
 }
@@ -1201,19 +1191,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
 }
 
 namespace {
-struct Ctx {
-  BlockedWorkspace* ws;
-  long long nc;
-  hipStream_t st;
-  int32_t* info;
-  int stepcode;
-};
-
 inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + bs - 1) / bs); }
+}  // namespace
 
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
-          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0,
-          double* Ct = nullptr) {
+          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly, double* Ct) {
   const int min128 = c.ws->gemm128_min;  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
   const bool big = M >= min128 && N >= min128;
   const int TM = big ? 128 : 64;
@@ -1239,6 +1221,7 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
 #undef HOMMX_GT
 }
 
+namespace {
 void right_mult_Et(const Ctx& c, const double* IN, double* OUT, int nrows, int rowPlane, double alpha,
                    int olast = -1, int accumulate = 0) {
   const Geo& G = c.ws->G;
@@ -1284,21 +1267,24 @@ void left_mult_E(const Ctx& c, const double* X, double* OUT, int rowPlane, doubl
 #undef HOMMX_LM
 }
 
-// in-place inverse of the SPD diagonal block [off, off+size) of every cell's matrix S (ld = Bp), recursive
-// Schur-complement form; `tmp` points at free scratch (consumed stack-like by the nesting levels)
+}  // namespace
+
+// in-place inverse of the SPD diagonal block [off, off+size) of every matrix of the batch (ld / batch stride from the context,
+// default Bp / Bp^2), recursive Schur-complement form; `tmp` points at free scratch (consumed stack-like by the nesting levels)
 void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
   const Geo& G = c.ws->G;
-  const int ld = G.Bp;
-  const long long sS = (long long)G.Bp * G.Bp;
+  const int ld = c.ld ? c.ld : G.Bp;
+  const long long sS = c.sS ? c.sS : (long long)G.Bp * G.Bp;
+  const long long sT = c.sT ? c.sT : sS;
   if (size <= 32) {
     if (size == 32)
-      hipLaunchKernelGGL(k_leaf_inverse<32>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
+      hipLaunchKernelGGL(k_leaf_inverse<32>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode, c.infoDiv);
     else
-      hipLaunchKernelGGL(k_leaf_inverse<16>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
+      hipLaunchKernelGGL(k_leaf_inverse<16>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode, c.infoDiv);
     return;
   }
   if (size == 64 && !c.ws->leaf32) {
-    hipLaunchKernelGGL(k_leaf_inverse_blk<64>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode);
+    hipLaunchKernelGGL(k_leaf_inverse_blk<64>, dim3((unsigned)c.nc), dim3(64), 0, c.st, S, ld, sS, off, c.info, c.stepcode, c.infoDiv);
     return;
   }
   int s1 = (size / 2) / 32 * 32;
@@ -1309,20 +1295,49 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
   double* A21 = S + (long long)(off + s1) * ld + off;
   double* A12 = S + (long long)off * ld + off + s1;
   double* A22 = S + (long long)(off + s1) * ld + off + s1;
-  double* Xm = tmp;  // s2 x s1, ld = s1, batch stride sS (scratch matrices are Bp x Bp per cell)
+  double* Xm = tmp;  // s2 x s1, ld = s1, batch stride sT
   invert(c, S, off, s1, tmp);                                                  // A11 <- A11^-1
-  gemm(c, false, false, s2, s1, s1, 1.0, A21, ld, sS, A11, ld, sS, 0.0, Xm, s1, sS);   // Xm = A21 A11^-1
-  gemm(c, false, true, s2, s2, s1, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A22, ld, sS, 1);  // A22 <- A22 - Xm A21^T (symmetric: lower tiles;
+  gemm(c, false, false, s2, s1, s1, 1.0, A21, ld, sS, A11, ld, sS, 0.0, Xm, s1, sT);   // Xm = A21 A11^-1
+  gemm(c, false, true, s2, s2, s1, -1.0, Xm, s1, sT, A21, ld, sS, 1.0, A22, ld, sS, 1);  // A22 <- A22 - Xm A21^T (symmetric: lower tiles;
                                                                                           //  the recursion below never reads above the diagonal tiles)
   invert(c, S, off + s1, s2, tmp + (long long)s1 * s2);                        // A22 <- (Schur)^-1
-  gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sS, 0.0, A21, ld, sS, 0, A12);  // A21 <- -T^-1 Xm, A12 <- A21^T
-  gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sS, A21, ld, sS, 1.0, A11, ld, sS, 1, A11);  // A11 <- A11^-1 - Xm^T A21: symmetric
+  gemm(c, false, false, s2, s1, s2, -1.0, A22, ld, sS, Xm, s1, sT, 0.0, A21, ld, sS, 0, A12);  // A21 <- -T^-1 Xm, A12 <- A21^T
+  gemm(c, true, false, s1, s1, s2, -1.0, Xm, s1, sT, A21, ld, sS, 1.0, A11, ld, sS, 1, A11);  // A11 <- A11^-1 - Xm^T A21: symmetric
                                                                          // (= A11^-1 + Xm^T T^-1 Xm): lower tiles, mirrored in place
 }
-}  // namespace
+
+void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st) {
+  const Geo& G = ws->G;
+  // ---- K1: the stencil row of a node (3D elasticity: of one row component of a node) in registers, written once, no memset
+  {
+#define HOMMX_ASMR(D_, K_, SPLIT_)                                                                                          \
+  hipLaunchKernelGGL((k_assemble_reg<D_, K_, SPLIT_>), dim3(nblk(nc * G.nn * (SPLIT_ ? D_ : 1), 128)), dim3(128), 0, st, G, coef, Mm, \
+                     ws->Kst, ws->Brhs, nc)
+    if (G.dim == 2) {
+      if (G.kind == 0) HOMMX_ASMR(2, 0, 0); else if (G.kind == 1) HOMMX_ASMR(2, 1, 0); else if (G.kind == 2) HOMMX_ASMR(2, 2, 0); else HOMMX_ASMR(2, 3, 0);
+    } else {
+      if (G.kind == 0) HOMMX_ASMR(3, 0, 0); else if (G.kind == 1) HOMMX_ASMR(3, 1, 0); else if (G.kind == 2) HOMMX_ASMR(3, 2, 1); else HOMMX_ASMR(3, 3, 1);
+    }
+#undef HOMMX_ASMR
+  }
+  {
+#define HOMMX_C0(D_, K_)                                                                                                  \
+  do {                                                                                                                    \
+    if (G.n_el <= 4096) hipLaunchKernelGGL((k_c0<D_, K_, 1>), dim3(nblk(nc, 4)), dim3(256), 0, st, G, coef, ws->C0, nc);   \
+    else hipLaunchKernelGGL((k_c0<D_, K_, 4>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0, nc);                 \
+  } while (0)
+    if (G.dim == 2) {
+      if (G.kind == 0) HOMMX_C0(2, 0); else if (G.kind == 1) HOMMX_C0(2, 1); else if (G.kind == 2) HOMMX_C0(2, 2); else HOMMX_C0(2, 3);
+    } else {
+      if (G.kind == 0) HOMMX_C0(3, 0); else if (G.kind == 1) HOMMX_C0(3, 1); else if (G.kind == 2) HOMMX_C0(3, 2); else HOMMX_C0(3, 3);
+    }
+#undef HOMMX_C0
+  }
+}
 
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out,
                   int32_t* d_info, hipStream_t st, double* d_corr) {
+  if (ws->mf && !d_corr) return mf_solve(ws, ncells, d_coef, d_M, d_out, d_info, st);  // nested dissection (multifrontal.hip)
   if (int rc = ws_reserve(ws, ncells, d_corr != nullptr)) return rc;
   const Geo& G = ws->G;
   const int n = G.n, Bp = G.Bp;
@@ -1338,31 +1353,7 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
     const double* coef = d_coef + c0 * G.n_el * G.ncomp;
     const double* Mm = d_M ? d_M + c0 * G.dim * G.dim : nullptr;
-    // ---- K1: the stencil row of a node (3D elasticity: of one row component of a node) in registers, written once, no memset
-    {
-#define HOMMX_ASMR(D_, K_, SPLIT_)                                                                                          \
-  hipLaunchKernelGGL((k_assemble_reg<D_, K_, SPLIT_>), dim3(nblk(nc * G.nn * (SPLIT_ ? D_ : 1), 128)), dim3(128), 0, st, G, coef, Mm, \
-                     ws->Kst, ws->Brhs, nc)
-      if (G.dim == 2) {
-        if (G.kind == 0) HOMMX_ASMR(2, 0, 0); else if (G.kind == 1) HOMMX_ASMR(2, 1, 0); else if (G.kind == 2) HOMMX_ASMR(2, 2, 0); else HOMMX_ASMR(2, 3, 0);
-      } else {
-        if (G.kind == 0) HOMMX_ASMR(3, 0, 0); else if (G.kind == 1) HOMMX_ASMR(3, 1, 0); else if (G.kind == 2) HOMMX_ASMR(3, 2, 1); else HOMMX_ASMR(3, 3, 1);
-      }
-#undef HOMMX_ASMR
-    }
-    {
-#define HOMMX_C0(D_, K_)                                                                                                  \
-  do {                                                                                                                    \
-    if (G.n_el <= 4096) hipLaunchKernelGGL((k_c0<D_, K_, 1>), dim3(nblk(nc, 4)), dim3(256), 0, st, G, coef, ws->C0, nc);   \
-    else hipLaunchKernelGGL((k_c0<D_, K_, 4>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0, nc);                 \
-  } while (0)
-      if (G.dim == 2) {
-        if (G.kind == 0) HOMMX_C0(2, 0); else if (G.kind == 1) HOMMX_C0(2, 1); else if (G.kind == 2) HOMMX_C0(2, 2); else HOMMX_C0(2, 3);
-      } else {
-        if (G.kind == 0) HOMMX_C0(3, 0); else if (G.kind == 1) HOMMX_C0(3, 1); else if (G.kind == 2) HOMMX_C0(3, 2); else HOMMX_C0(3, 3);
-      }
-#undef HOMMX_C0
-    }
+    launch_assembly(ws, coef, Mm, nc, st);
     if (G.b <= 64 && !d_corr && ws->small_fused) {
       // small plane blocks: the whole elimination in ONE launch -- b <= 48: one wave per macro cell, matrices in registers
       // (small_wave.h); 48 < b <= 64, or HOMMX_SMALL_WAVES = 2 | 4: that many waves per cell, matrices in LDS (small_fused.h)

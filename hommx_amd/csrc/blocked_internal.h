@@ -1,0 +1,71 @@
+// blocked_internal.h -- shared between blocked.hip (block-cyclic plane elimination) and multifrontal.hip (nested dissection):
+// the workspace object behind a plan of the blocked family and the batched fp64-MFMA building blocks (GEMM tiles, recursive
+// block inverse) both eliminations are made of.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "geo.h"
+
+namespace hommx {
+
+struct MfPlan;  // multifrontal.hip
+
+struct BlockedWorkspace {
+  Geo G;
+  // development knobs, read ONCE when the plan is created (include/hommx_hip.h lists them)
+  double budget_gb_env = 0.0;  // HOMMX_BLOCKED_MEM_GB (0: automatic)
+  int gemm128_min = 256;       // HOMMX_GEMM128_MIN
+  bool sparse_v1 = false;      // HOMMX_SPARSE_V1: generic instead of strip-form sparse E products
+  bool leaf32 = false;         // HOMMX_LEAF32: 32x32 leaves only in the recursive inverse
+  bool split64 = true;         // HOMMX_NO_SPLIT64: halve 192 into 96 + 96 (32- and 64-leaves) instead of 64 + 128
+  bool small_fused = true;     // HOMMX_NO_SMALL_FUSED switches the LDS-resident kernel for b <= 64 off (A/B runs)
+  int small_waves = 0;         // HOMMX_SMALL_WAVES: 2 / 4 = the LDS kernel with that many waves per macro cell; 0 = default routes
+  long long chunk = 0;
+  double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;
+  double *S = nullptr, *W = nullptr, *Sl = nullptr, *V = nullptr, *X = nullptr, *T = nullptr;
+  double *R = nullptr, *Rl = nullptr, *Vr = nullptr, *Gm = nullptr;
+  // corrector mode: per eliminated plane the inverse Schur block, the arrow block and the load rows are kept
+  long long hchunk = 0;
+  double *hS = nullptr, *hW = nullptr, *hR = nullptr, *Xa = nullptr, *Xb = nullptr, *Y = nullptr;
+  // nested-dissection route (3D, large plane blocks): symbolic analysis + arena, owned by multifrontal.hip
+  MfPlan* mf = nullptr;
+  int mf_min_b = 192;          // HOMMX_MF_MIN_B: smallest plane block b routed to the multifrontal elimination (0: never)
+};
+
+
+// One batched operation context: `nc` matrices (cells, or cells x fronts of one shape) on stream `st`.
+struct Ctx {
+  BlockedWorkspace* ws;
+  long long nc;
+  hipStream_t st;
+  int32_t* info;          // per CELL failure flags (nullable)
+  int stepcode;           // value a failing pivot check writes into info
+  int ld = 0;             // leading dimension of the matrices invert() works on (0: G.Bp)
+  long long sS = 0;       // their batch stride (0: Bp * Bp)
+  long long sT = 0;       // batch stride of invert()'s scratch (0: sS)
+  int infoDiv = 1;        // info index = batch index / infoDiv (fronts per cell in the multifrontal route)
+};
+
+// C = alpha op(A) op(B) + beta C for every matrix of the batch (blocked.hip: k_gemm_tile, XCD-aware tiles); lowerOnly: tiles on and
+// below the diagonal only; Ct: mirrored copy of the result (may be C itself with lowerOnly)
+void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA, const double* B,
+          int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0, double* Ct = nullptr);
+
+// in-place inverse of the SPD diagonal block [off, off + size) of every matrix of the batch (recursive Schur-complement form;
+// size a multiple of 32); `tmp`: scratch of at least size^2 / 2 doubles per matrix, batch stride c.sT
+void invert(const Ctx& c, double* S, int off, int size, double* tmp);
+
+extern thread_local std::string g_berr;
+
+// multifrontal.hip
+int mf_plan_create(MfPlan** out, const Geo& G);
+void mf_plan_destroy(MfPlan* p);
+int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
+             hipStream_t st);
+// K1 of the blocked family (stencil rows, loads, C0 of `nc` cells into ws->Kst / Brhs / C0), shared by both eliminations
+void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st);
+
+}  // namespace hommx

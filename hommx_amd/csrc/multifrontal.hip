@@ -1,0 +1,684 @@
+// multifrontal.hip -- nested-dissection (multifrontal) elimination of the periodic micro problem for LARGE plane blocks (3D, b >= 192:
+// BASELINE configurations C4 / C5, 16^3 micro cells x 3 components = 12,288 unknowns per macro cell).
+//
+// Why: the block-cyclic plane elimination of blocked.hip carries a dense b x b arrow through n - 1 steps, (6 (n-1) + 2) b^3 model flops
+// (41.7 GFLOP per C4 / C5 cell); a sparse Cholesky under nested dissection needs 11.3 GFLOP (profiles/fref.json).  Here the torus is
+// dissected geometrically -- two planes per periodic direction, one per open direction, down to 3 x 3 x 3-node leaves -- and every
+// supernode (separator or leaf) is eliminated as a dense FRONT
+//
+//        F = [ F11  F12 ]   s = the supernode's unknowns, r = the later-eliminated unknowns it touches (its "boundary")
+//            [ F21  F22 ]
+//        N = F11^-1 ;  F12 <- N F21^T ;  F22 <- F22 - F21 F12 (lower tiles) ;  load rows: Vr = R_s N, G_f = Vr R_s^T, R_r -= Vr F21^T
+//
+// with the SAME batched fp64-MFMA building blocks as the plane elimination (blocked.hip: k_gemm_tile, recursive block inverse).  All macro
+// cells share the structure, and fronts of equal shape at equal height of the elimination tree are independent, so every step is ONE
+// batched launch over (cells x fronts of that shape).  The update matrix F22 of a child is added into its parent while the parent's
+// front is WRITTEN (k_mf_build gathers: original stencil entries + the children's F22 entries, every entry written exactly once -- no
+// memset, no atomics); nodes are numbered in elimination order everywhere, so child -> parent index maps are monotone and only lower
+// triangles are ever needed.  Effective tensor: A_H = C0 - sum over fronts G_f  (= C0 - B^T K^+ B; reference forms
+// hmm.py:644-667 / 759-789 / 887-922 / 1024-1067); gauge: the last node is pinned in the root front (cell_problem.py:349-361).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "../../include/hommx_hip.h"
+#include "blocked_internal.h"
+#include "kernels.h"
+
+namespace hommx {
+
+#define MTRY(expr)                                                                       \
+  do {                                                                                   \
+    hipError_t e__ = (expr);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      g_berr = std::string(#expr) + ": " + hipGetErrorString(e__);                       \
+      return e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP;                     \
+    }                                                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// plan: symbolic analysis (host) + index tables (device)
+// ---------------------------------------------------------------------------------------------------------------
+struct MfChild {            // one child slot of a front, as the build kernels see it
+  long long offF, offR;     // per-cell arena offsets (doubles) of the child's GROUP buffers (x chunk size at launch)
+  int nf, fidx, L, sp;      // fronts in the child's group, the child's index in it, its leading dimension, its padded s
+  int valid, pad;
+};
+
+struct MfGroup {
+  int height = 0, ns = 0, nr = 0;   // nodes eliminated here / boundary nodes
+  int sp = 0, rp = 0, L = 0;        // padded unknown counts (sp: multiple of 32; rp: multiple of 16), L = sp + rp
+  int nf = 0;                       // fronts of this shape at this height
+  int goff = 0;                     // first slot of the group in the per-front G_f array
+  long long offF = 0, offR = 0;     // per-cell arena offsets (doubles): F [nf][L][L], R [nf][16][L]
+  int pinpos = -1;                  // root only: local node whose unknowns are pinned (gauge)
+  // device tables, [nf] x ...
+  int32_t* d_nodes = nullptr;       // [nf][nloc]      global (periodic) node of local node
+  int8_t* d_code = nullptr;         // [nf][nloc][ns]  stencil code of (row node i, column node j < ns), -1: no coupling
+  int32_t* d_cpos = nullptr;        // [nf][2][nloc]   position of local node in child c's boundary list, -1: not there
+  MfChild* d_child = nullptr;       // [nf][2]
+};
+
+struct MfPlan {
+  Geo G;
+  std::vector<MfGroup> groups;      // in processing order (height ascending)
+  int nfronts = 0;
+  long long arena_per_cell = 0;     // doubles: fronts + load rows, lifetimes overlapped
+  long long scratch_per_cell = 0;   // doubles: inverse scratch + Vr of the largest group
+  double flops_per_cell = 0.0;      // executed by the model s^3 + 2 s^2 r + s r^2 on the padded sizes
+  // chunk buffers
+  long long chunk = 0;
+  double *arena = nullptr, *scratch = nullptr, *Gf = nullptr;
+  int* d_goff = nullptr;
+};
+
+namespace {
+
+struct SN {
+  std::vector<int> nodes, children, bnd;
+  int height = 0, group = -1, fidx = -1;
+};
+
+struct TreeBuilder {
+  int dim, n, leaf_max;
+  std::vector<SN> sn;
+  int coord(int node, int ax) const {
+    for (int k = 0; k < ax; ++k) node /= n;
+    return node % n;
+  }
+  // nested dissection of the box [lo, hi) (periodic[ax]: the box is the whole ring in that direction); returns the top supernode
+  int rec(const std::vector<int>& sel, const int* lo, const int* hi, const bool* periodic) {
+    if (sel.empty()) return -1;
+    int size[3] = {1, 1, 1}, mx = 0;
+    for (int a = 0; a < dim; ++a) {
+      size[a] = hi[a] - lo[a];
+      mx = std::max(mx, size[a]);
+    }
+    if ((int)sel.size() <= leaf_max || mx <= 2) {
+      SN s;
+      s.nodes = sel;
+      sn.push_back(s);
+      return (int)sn.size() - 1;
+    }
+    int ax = 0;
+    for (int a = 1; a < dim; ++a)
+      if (size[a] > size[ax]) ax = a;
+    int l1[3], h1[3], l2[3], h2[3];
+    bool per2[3];
+    for (int a = 0; a < 3; ++a) {
+      l1[a] = l2[a] = lo[a];
+      h1[a] = h2[a] = hi[a];
+      per2[a] = periodic[a];
+    }
+    std::vector<int> a_, b_, sepA, sepB;
+    if (periodic[ax]) {  // a ring needs two cuts: the last plane and the middle one
+      const int cutA = hi[ax] - 1, cutB = lo[ax] + (size[ax] - 1) / 2;
+      for (int v : sel) {
+        const int c = coord(v, ax);
+        if (c == cutA) sepA.push_back(v);
+        else if (c == cutB) sepB.push_back(v);
+        else if (c < cutB) a_.push_back(v);
+        else b_.push_back(v);
+      }
+      per2[ax] = false;
+      h1[ax] = cutB;
+      l2[ax] = cutB + 1;
+      h2[ax] = cutA;
+    } else {
+      const int mid = lo[ax] + size[ax] / 2;
+      for (int v : sel) {
+        const int c = coord(v, ax);
+        if (c == mid) sepA.push_back(v);
+        else if (c < mid) a_.push_back(v);
+        else b_.push_back(v);
+      }
+      h1[ax] = mid;
+      l2[ax] = mid + 1;
+    }
+    const int ca = rec(a_, l1, h1, per2), cb = rec(b_, l2, h2, per2);
+    // the two planes of a ring cut are eliminated one after the other (a chain: an s-sized inverse costs s^3, two halves a quarter of it)
+    int top = -1;
+    if (!sepB.empty()) {
+      SN s;
+      s.nodes = sepB;
+      if (ca >= 0) s.children.push_back(ca);
+      if (cb >= 0) s.children.push_back(cb);
+      sn.push_back(s);
+      top = (int)sn.size() - 1;
+    }
+    SN s;
+    s.nodes = sepA;
+    if (top >= 0) s.children.push_back(top);
+    else {
+      if (ca >= 0) s.children.push_back(ca);
+      if (cb >= 0) s.children.push_back(cb);
+    }
+    sn.push_back(s);
+    return (int)sn.size() - 1;
+  }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& src) {
+  *dst = nullptr;
+  if (src.empty()) return 0;
+  MTRY(hipMalloc(dst, sizeof(T) * src.size()));
+  MTRY(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+void mf_plan_destroy(MfPlan* p) {
+  if (!p) return;
+  for (MfGroup& g : p->groups) {
+    if (g.d_nodes) (void)hipFree(g.d_nodes);
+    if (g.d_code) (void)hipFree(g.d_code);
+    if (g.d_cpos) (void)hipFree(g.d_cpos);
+    if (g.d_child) (void)hipFree(g.d_child);
+  }
+  if (p->arena) (void)hipFree(p->arena);
+  if (p->scratch) (void)hipFree(p->scratch);
+  if (p->Gf) (void)hipFree(p->Gf);
+  if (p->d_goff) (void)hipFree(p->d_goff);
+  delete p;
+}
+
+int mf_plan_create(MfPlan** out, const Geo& G) {
+  *out = nullptr;
+  MfPlan* P = new MfPlan();
+  P->G = G;
+  const int dim = G.dim, n = G.n, bs = G.bs, nn = G.nn;
+  TreeBuilder tb;
+  tb.dim = dim;
+  tb.n = n;
+  tb.leaf_max = dim == 3 ? 27 : 9;
+  if (const char* e = getenv("HOMMX_MF_LEAF")) tb.leaf_max = std::max(1, atoi(e));
+  {
+    std::vector<int> all(nn);
+    for (int i = 0; i < nn; ++i) all[i] = i;
+    const int lo[3] = {0, 0, 0}, hi[3] = {n, n, dim == 3 ? n : 1};
+    const bool per[3] = {true, true, dim == 3};
+    tb.rec(all, lo, hi, per);
+  }
+  std::vector<SN>& sn = tb.sn;
+  const int nsn = (int)sn.size();
+  // elimination rank of every node: supernodes in list order (children before parents), ascending node id inside
+  std::vector<int> rank(nn, -1), owner(nn, -1);
+  {
+    int r = 0;
+    for (int k = 0; k < nsn; ++k) {
+      std::sort(sn[k].nodes.begin(), sn[k].nodes.end());
+      for (int v : sn[k].nodes) {
+        rank[v] = r++;
+        owner[v] = k;
+      }
+    }
+  }
+  // stencil offsets: code = sum (d_k + 1) 3^k; the periodic P1 stencil couples along the cube's main-diagonal tetrahedra only
+  // (offsets whose components all have one sign), but the table keeps every code the assembly kernel writes (zeros included)
+  const int ncode = G.ncode;
+  auto neighbour = [&](int v, int code) {
+    int out = 0, mul = 1, vv = v, cc = code;
+    for (int k = 0; k < dim; ++k) {
+      const int c = vv % n, d = cc % 3 - 1;
+      out += ((c + d + n) % n) * mul;
+      mul *= n;
+      vv /= n;
+      cc /= 3;
+    }
+    return out;
+  };
+  auto coupled = [&](int code) {  // offsets of the 7- / 15-point stencil (all components >= 0 or all <= 0)
+    bool pos = false, neg = false;
+    int cc = code;
+    for (int k = 0; k < dim; ++k) {
+      const int d = cc % 3 - 1;
+      pos |= d > 0;
+      neg |= d < 0;
+      cc /= 3;
+    }
+    return !(pos && neg);
+  };
+  // boundaries (symbolic elimination on the supernode tree) and heights
+  {
+    std::vector<char> mark(nn, 0);
+    for (int k = 0; k < nsn; ++k) {
+      SN& s = sn[k];
+      std::vector<int> cand;
+      for (int v : s.nodes)
+        for (int code = 0; code < ncode; ++code)
+          if (coupled(code)) cand.push_back(neighbour(v, code));
+      for (int c : s.children) {
+        cand.insert(cand.end(), sn[c].bnd.begin(), sn[c].bnd.end());
+        s.height = std::max(s.height, sn[c].height + 1);
+      }
+      for (int v : cand)
+        if (owner[v] > k && !mark[v]) {
+          mark[v] = 1;
+          s.bnd.push_back(v);
+        }
+      for (int v : s.bnd) mark[v] = 0;
+      std::sort(s.bnd.begin(), s.bnd.end(), [&](int a, int b) { return rank[a] < rank[b]; });
+    }
+  }
+  if (owner[nn - 1] != nsn - 1) {
+    g_berr = "multifrontal plan: the gauge node is not in the root front";
+    delete P;
+    return HOMMX_EINVAL;
+  }
+  // groups: fronts of equal (height, ns, nr)
+  std::map<std::tuple<int, int, int>, int> gid;
+  std::vector<std::vector<int>> members;
+  for (int k = 0; k < nsn; ++k) {
+    auto key = std::make_tuple(sn[k].height, (int)sn[k].nodes.size(), (int)sn[k].bnd.size());
+    auto it = gid.find(key);
+    if (it == gid.end()) {
+      it = gid.emplace(key, (int)members.size()).first;
+      members.emplace_back();
+    }
+    sn[k].group = it->second;
+    sn[k].fidx = (int)members[it->second].size();
+    members[it->second].push_back(k);
+  }
+  const int ng = (int)members.size();  // std::map iteration order = (height, ns, nr) ascending = a valid processing order
+  std::vector<int> order;
+  for (auto& kv : gid) order.push_back(kv.second);
+  std::vector<int> pos_of(ng);
+  for (int t = 0; t < ng; ++t) pos_of[order[t]] = t;
+  P->groups.resize(ng);
+  P->nfronts = nsn;
+  // sizes, lifetimes, arena offsets (first fit over the live intervals)
+  std::vector<int> expiry(ng);
+  for (int t = 0; t < ng; ++t) {
+    const int g = order[t];
+    MfGroup& mg = P->groups[t];
+    const SN& s0 = sn[members[g][0]];
+    mg.height = s0.height;
+    mg.ns = (int)s0.nodes.size();
+    mg.nr = (int)s0.bnd.size();
+    mg.sp = round_up(mg.ns * bs, 32);
+    mg.rp = round_up(mg.nr * bs, 16);
+    mg.L = mg.sp + mg.rp;
+    mg.nf = (int)members[g].size();
+    expiry[t] = t;
+  }
+  for (int k = 0; k < nsn; ++k)
+    for (int c : sn[k].children) expiry[pos_of[sn[c].group]] = std::max(expiry[pos_of[sn[c].group]], pos_of[sn[k].group]);
+  {
+    struct Live {
+      long long off, size;
+      int expiry;
+    };
+    std::vector<Live> live;
+    long long peak = 0;
+    auto place = [&](long long size, int exp_, int now) {
+      live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.expiry < now; }), live.end());
+      std::sort(live.begin(), live.end(), [](const Live& a, const Live& b) { return a.off < b.off; });
+      long long off = 0;
+      for (const Live& l : live) {
+        if (off + size <= l.off) break;
+        off = std::max(off, l.off + l.size);
+      }
+      live.push_back({off, size, exp_});
+      peak = std::max(peak, off + size);
+      return off;
+    };
+    int goff = 0;
+    for (int t = 0; t < ng; ++t) {
+      MfGroup& mg = P->groups[t];
+      mg.offF = place((long long)mg.nf * mg.L * mg.L, expiry[t], t);
+      mg.offR = place((long long)mg.nf * 16 * mg.L, expiry[t], t);
+      mg.goff = goff;
+      goff += mg.nf;
+      P->scratch_per_cell = std::max(P->scratch_per_cell, (long long)mg.nf * ((long long)mg.sp * mg.sp + 16ll * mg.sp));
+      const double s = mg.sp, r = mg.rp;
+      P->flops_per_cell += mg.nf * (s * s * s + 2.0 * s * s * r + s * r * r);
+    }
+    P->arena_per_cell = peak;
+  }
+  // device tables
+  std::vector<int> local(nn, -1);
+  for (int t = 0; t < ng; ++t) {
+    const int g = order[t];
+    MfGroup& mg = P->groups[t];
+    const int nloc = mg.ns + mg.nr;
+    std::vector<int32_t> nodes((size_t)mg.nf * nloc), cpos((size_t)mg.nf * 2 * nloc, -1);
+    std::vector<int8_t> code((size_t)mg.nf * nloc * mg.ns, (int8_t)-1);
+    std::vector<MfChild> child((size_t)mg.nf * 2);
+    for (int f = 0; f < mg.nf; ++f) {
+      const SN& s = sn[members[g][f]];
+      int32_t* nd = &nodes[(size_t)f * nloc];
+      for (int i = 0; i < mg.ns; ++i) nd[i] = s.nodes[i];
+      for (int i = 0; i < mg.nr; ++i) nd[mg.ns + i] = s.bnd[i];
+      for (int i = 0; i < nloc; ++i) local[nd[i]] = i;
+      for (int j = 0; j < mg.ns; ++j)  // column node j: its stencil neighbours i = j + off(code'), stored as the code of (i -> j)
+        for (int c = 0; c < ncode; ++c) {
+          if (!coupled(c)) continue;
+          const int v = neighbour(nd[j], c);  // v = node_j + off(c)  =>  node_j = v + off(opposite code)
+          const int i = local[v];
+          if (i < 0) continue;  // eliminated earlier: that coupling sits in an earlier front
+          code[((size_t)f * nloc + i) * mg.ns + j] = (int8_t)(ncode - 1 - c);  // opposite offset: code of (node_i -> node_j)
+        }
+      for (int slot = 0; slot < 2; ++slot) {
+        MfChild& ch = child[(size_t)f * 2 + slot];
+        ch = MfChild{0, 0, 0, 0, 0, 0, 0, 0};
+        if (slot >= (int)s.children.size()) continue;
+        const SN& cs = sn[s.children[slot]];
+        const MfGroup& cg = P->groups[pos_of[cs.group]];
+        ch.offF = cg.offF;
+        ch.offR = cg.offR;
+        ch.nf = cg.nf;
+        ch.fidx = cs.fidx;
+        ch.L = cg.L;
+        ch.sp = cg.sp;
+        ch.valid = 1;
+        for (int q = 0; q < (int)cs.bnd.size(); ++q) {
+          const int i = local[cs.bnd[q]];
+          if (i < 0) {
+            g_berr = "multifrontal plan: a child's boundary node is missing from its parent's front";
+            mf_plan_destroy(P);
+            return HOMMX_EINVAL;
+          }
+          cpos[((size_t)f * 2 + slot) * nloc + i] = q;
+        }
+      }
+      if (s.children.size() > 2) {
+        g_berr = "multifrontal plan: more than two children";
+        mf_plan_destroy(P);
+        return HOMMX_EINVAL;
+      }
+      if (members[g][f] == nsn - 1) mg.pinpos = local[nn - 1];
+      for (int i = 0; i < nloc; ++i) local[nd[i]] = -1;
+    }
+    if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_child, child)) {
+      mf_plan_destroy(P);
+      return HOMMX_EHIP;
+    }
+  }
+  {
+    std::vector<int> goff;
+    for (const MfGroup& mg : P->groups) {
+      goff.push_back(mg.goff);
+      goff.push_back(mg.nf);
+    }
+    if (upload(&P->d_goff, goff)) {
+      mf_plan_destroy(P);
+      return HOMMX_EHIP;
+    }
+  }
+  if (getenv("HOMMX_MF_VERBOSE")) {
+    fprintf(stderr, "[hommx multifrontal] n = %d, bs = %d: %d fronts in %d groups, arena %.1f MB + scratch %.1f MB per cell, %.2f GFLOP per cell\n",
+            n, bs, nsn, ng, 8e-6 * P->arena_per_cell, 8e-6 * P->scratch_per_cell, 1e-9 * P->flops_per_cell);
+    for (const MfGroup& mg : P->groups)
+      fprintf(stderr, "   height %d: %3d fronts  s = %4d (%4d)  r = %4d (%4d)\n", mg.height, mg.nf, mg.ns * bs, mg.sp, mg.nr * bs, mg.rp);
+  }
+  *out = P;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------
+struct MfGroupDev {
+  int ns, nloc, sp, L, nf;
+  long long offF, offR;   // per-cell arena offsets of this group's F and R buffers
+  const int32_t* nodes;
+  const int8_t* code;
+  const int32_t* cpos;
+  const MfChild* child;
+};
+
+// The front of every (cell, front) of the group, lower triangle (F11 complete): original stencil entries of the columns eliminated
+// here + the children's update matrices.  One thread per pair of local nodes (i >= j): a BS x BS block.
+template <int BS>
+__global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, double* __restrict__ arena, long long nc,
+                                                  int nn, int ncode, int jblocks) {
+  const int tid = threadIdx.x;
+  long long blk = blockIdx.x;
+  const int jb = (int)(blk % jblocks);
+  blk /= jblocks;
+  const int ib = (int)(blk % ((g.nloc + 3) / 4));
+  const long long batch = blk / ((g.nloc + 3) / 4);
+  const int i = ib * 4 + (tid >> 6), j = jb * 64 + (tid & 63);
+  if (i >= g.nloc || j > i) return;
+  const long long cell = batch / g.nf;
+  const int f = (int)(batch % g.nf);
+  double v[BS][BS];
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = 0; b < BS; ++b) v[a][b] = 0.0;
+  const int32_t* nodes = g.nodes + (long long)f * g.nloc;
+  if (j < g.ns) {
+    const int code = g.code[((long long)f * g.nloc + i) * g.ns + j];
+    if (code >= 0) {
+      const double* Kc = Kst + ((cell * ncode + code) * BS) * BS * (long long)nn + nodes[i];
+#pragma unroll
+      for (int a = 0; a < BS; ++a)
+#pragma unroll
+        for (int b = 0; b < BS; ++b) v[a][b] = Kc[((long long)a * BS + b) * nn];
+    }
+  }
+#pragma unroll
+  for (int slot = 0; slot < 2; ++slot) {
+    const MfChild ch = g.child[f * 2 + slot];
+    if (!ch.valid) continue;
+    const int32_t* cp = g.cpos + ((long long)f * 2 + slot) * g.nloc;
+    const int ci = cp[i], cj = cp[j];
+    if (ci < 0 || cj < 0) continue;
+    const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
+    // only entries on and below the diagonal of the child's update matrix are valid (its GEMM updates lower TILES, and a BS x BS
+    // diagonal block may straddle a tile boundary): a diagonal block is read through its lower triangle
+    const bool diag = ci == cj;
+#pragma unroll
+    for (int a = 0; a < BS; ++a)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) {
+        const int ra = (diag && b > a) ? b : a, rb = (diag && b > a) ? a : b;
+        v[a][b] += U[(long long)(ci * BS + ra) * ch.L + cj * BS + rb];
+      }
+  }
+  double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+  const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS, rj = j < g.ns ? j * BS : g.sp + (j - g.ns) * BS;
+#pragma unroll
+  for (int a = 0; a < BS; ++a)
+#pragma unroll
+    for (int b = 0; b < BS; ++b) F[(long long)(ri + a) * g.L + rj + b] = v[a][b];
+  if (i < g.ns && i != j) {  // F11 is kept complete (the leaf inverses read whole diagonal blocks)
+#pragma unroll
+    for (int a = 0; a < BS; ++a)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) F[(long long)(rj + b) * g.L + ri + a] = v[a][b];
+  }
+}
+
+// padding of the eliminated block (identity) and of the boundary rows (zeros); root: the gauge node's unknowns are pinned
+template <int BS>
+__global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int rreal, int pinpos) {
+  const int npad_s = g.sp - g.ns * BS, npad_r = (g.L - g.sp) - rreal, npin = pinpos >= 0 ? BS : 0;
+  const int lines = npad_s + npad_r + npin;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nc * g.nf * (long long)lines * g.L) return;
+  const int x = (int)(idx % g.L);
+  const int line = (int)((idx / g.L) % lines);
+  const long long batch = idx / ((long long)g.L * lines);
+  double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+  if (line < npad_s || line >= npad_s + npad_r) {  // a row + column of the eliminated block -> unit vector
+    const int p = line < npad_s ? g.ns * BS + line : pinpos * BS + (line - npad_s - npad_r);
+    if (x < g.sp) F[(long long)p * g.L + x] = x == p ? 1.0 : 0.0;
+    F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
+  } else {  // padding row of F21
+    const int p = g.sp + rreal + (line - npad_s);
+    if (x < g.sp) F[(long long)p * g.L + x] = 0.0;
+  }
+}
+
+// load rows R[16][L] of every (cell, front): the canonical loads of the columns eliminated here + the children's updated rows
+template <int BS>
+__global__ void k_mf_build_rhs(MfGroupDev g, const double* __restrict__ Brhs, double* __restrict__ arena, long long nc, int nn, int t,
+                               int rreal, int pinpos) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nc * g.nf * 16ll * g.L) return;
+  const int x = (int)(idx % g.L);
+  const int m = (int)((idx / g.L) % 16);
+  const long long batch = idx / (16ll * g.L);
+  const long long cell = batch / g.nf;
+  const int f = (int)(batch % g.nf);
+  double v = 0.0;
+  int i = -1, a = 0;
+  if (x < g.ns * BS) {
+    i = x / BS;
+    a = x % BS;
+  } else if (x >= g.sp && x < g.sp + rreal) {
+    i = g.ns + (x - g.sp) / BS;
+    a = (x - g.sp) % BS;
+  }
+  if (i >= 0 && m < t && i != pinpos) {
+    if (i < g.ns) v = Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + a) * nn + g.nodes[(long long)f * g.nloc + i]];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const MfChild ch = g.child[f * 2 + slot];
+      if (!ch.valid) continue;
+      const int ci = g.cpos[((long long)f * 2 + slot) * g.nloc + i];
+      if (ci < 0) continue;
+      v += arena[nc * ch.offR + (cell * ch.nf + ch.fidx) * 16ll * ch.L + (long long)m * ch.L + ch.sp + ci * BS + a];
+    }
+  }
+  arena[nc * g.offR + batch * 16ll * g.L + (long long)m * g.L + x] = v;
+}
+
+// A_H = C0 - sum over all fronts of G_f
+__global__ void k_mf_finalize(const double* __restrict__ C0, const double* __restrict__ Gf, const int* __restrict__ goff, int ngroups, int t,
+                              double* __restrict__ out, long long nc) {
+  const int tt = t * t;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nc * tt) return;
+  const long long cell = idx / tt;
+  const int m = (int)(idx % tt) / t, q = (int)(idx % tt) % t;
+  double acc = 0.0;
+  for (int g = 0; g < ngroups; ++g) {
+    const int off = goff[2 * g], nf = goff[2 * g + 1];
+    const double* p = Gf + (nc * off + cell * nf) * 256ll + m * 16 + q;
+    for (int f = 0; f < nf; ++f) acc += p[f * 256ll];
+  }
+  out[idx] = C0[idx] - acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------------------
+static int mf_reserve(BlockedWorkspace* ws, long long ncells) {
+  MfPlan* P = ws->mf;
+  const Geo& G = ws->G;
+  double budget_gb = 128.0;  // fronts are big (C4 / C5: 0.2 GB per cell) and the card has 288 GB
+  {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      const double have = 1e-9 * (double)fr + 8e-9 * (double)P->chunk * (P->arena_per_cell + P->scratch_per_cell);  // what is free + what we hold
+      budget_gb = std::min(budget_gb, 0.6 * have);
+    }
+  }
+  if (ws->budget_gb_env > 0.0) budget_gb = ws->budget_gb_env;
+  const long long stencil = (long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36;
+  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + 256ll * P->nfronts + stencil);
+  long long chunk = (long long)(budget_gb * 1e9) / per_cell;
+  if (chunk < 1) chunk = 1;
+  if (chunk > 4096) chunk = 4096;
+  if (chunk > ncells) chunk = ncells;
+  if (chunk <= P->chunk) return 0;
+  for (double** p : {&P->arena, &P->scratch, &P->Gf, &ws->Kst, &ws->Brhs, &ws->C0}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  P->chunk = 0;
+  MTRY(hipMalloc(&P->arena, 8ll * chunk * P->arena_per_cell));
+  MTRY(hipMalloc(&P->scratch, 8ll * chunk * P->scratch_per_cell));
+  MTRY(hipMalloc(&P->Gf, 8ll * chunk * 256 * P->nfronts));
+  MTRY(hipMalloc(&ws->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
+  MTRY(hipMalloc(&ws->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
+  MTRY(hipMalloc(&ws->C0, 8ll * chunk * 36));
+  P->chunk = chunk;
+  return 0;
+}
+
+static inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + bs - 1) / bs); }
+
+int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
+             hipStream_t st) {
+  MfPlan* P = ws->mf;
+  const Geo& G = ws->G;
+  if (int rc = mf_reserve(ws, ncells)) return rc;
+  if (d_info) MTRY(hipMemsetAsync(d_info, 0, sizeof(int32_t) * ncells, st));
+  long long step_cells = P->chunk;
+  {
+    const long long nchunks = (ncells + step_cells - 1) / step_cells;
+    step_cells = (ncells + nchunks - 1) / nchunks;
+  }
+  const int bs = G.bs;
+  for (long long c0 = 0; c0 < ncells; c0 += step_cells) {
+    const long long nc = std::min(step_cells, ncells - c0);
+    launch_assembly(ws, d_coef + c0 * G.n_el * G.ncomp, d_M ? d_M + c0 * G.dim * G.dim : nullptr, nc, st);
+    int gi = 0;
+    for (const MfGroup& mg : P->groups) {
+      ++gi;
+      const long long nb = nc * mg.nf;  // matrices in this batch
+      MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.L, mg.nf, mg.offF, mg.offR, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
+      const int jblocks = (gd.nloc + 63) / 64;
+      const long long bblocks = nb * ((gd.nloc + 3) / 4) * jblocks;
+      if (bblocks > 0x7fffffffll) {
+        g_berr = "multifrontal: build grid too large";
+        return HOMMX_EINVAL;
+      }
+      const int rreal = mg.nr * bs;
+      const int lines = (mg.sp - mg.ns * bs) + (mg.rp - rreal) + (mg.pinpos >= 0 ? bs : 0);
+#define HOMMX_MF_K(BS_)                                                                                                                        \
+  do {                                                                                                                                         \
+    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)bblocks), dim3(256), 0, st, gd, ws->Kst, P->arena, nc, G.nn, G.ncode, jblocks);          \
+    if (lines > 0)                                                                                                                             \
+      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3(nblk(nb * (long long)lines * mg.L)), dim3(256), 0, st, gd, P->arena, nc, rreal, mg.pinpos);       \
+    hipLaunchKernelGGL((k_mf_build_rhs<BS_>), dim3(nblk(nb * 16ll * mg.L)), dim3(256), 0, st, gd, ws->Brhs, P->arena, nc, G.nn, G.t, rreal,     \
+                       mg.pinpos);                                                                                                             \
+  } while (0)
+      if (bs == 1) HOMMX_MF_K(1);
+      else if (bs == 2) HOMMX_MF_K(2);
+      else HOMMX_MF_K(3);
+#undef HOMMX_MF_K
+      double* F = P->arena + nc * mg.offF;
+      double* R = P->arena + nc * mg.offR;
+      const long long sF = (long long)mg.L * mg.L, sR = 16ll * mg.L;
+      double* tmp = P->scratch;                                   // inverse scratch: sp^2 per matrix
+      double* Vr = P->scratch + nb * (long long)mg.sp * mg.sp;    // 16 x sp per matrix
+      double* Gg = P->Gf + nc * mg.goff * 256ll;
+      Ctx c{ws, nb, st, d_info ? d_info + c0 : nullptr, gi};
+      c.ld = mg.L;
+      c.sS = sF;
+      c.sT = (long long)mg.sp * mg.sp;
+      c.infoDiv = mg.nf;
+      invert(c, F, 0, mg.sp, tmp);                                                                               // F11 <- N = F11^-1
+      gemm(c, false, false, 16, mg.sp, mg.sp, 1.0, R, mg.L, sR, F, mg.L, sF, 0.0, Vr, mg.sp, 16ll * mg.sp);      // Vr = R_s N
+      gemm(c, false, true, 16, 16, mg.sp, 1.0, Vr, mg.sp, 16ll * mg.sp, R, mg.L, sR, 0.0, Gg, 16, 256);          // G_f = Vr R_s^T
+      if (mg.rp > 0) {
+        double* F21 = F + (long long)mg.sp * mg.L;
+        double* F12 = F + mg.sp;
+        double* F22 = F21 + mg.sp;
+        gemm(c, false, true, 16, mg.rp, mg.sp, -1.0, Vr, mg.sp, 16ll * mg.sp, F21, mg.L, sF, 1.0, R + mg.sp, mg.L, sR);   // R_r -= Vr F21^T
+        gemm(c, false, true, mg.sp, mg.rp, mg.sp, 1.0, F, mg.L, sF, F21, mg.L, sF, 0.0, F12, mg.L, sF);                   // F12 = N F21^T
+        gemm(c, false, false, mg.rp, mg.rp, mg.sp, -1.0, F21, mg.L, sF, F12, mg.L, sF, 1.0, F22, mg.L, sF, 1);           // F22 -= F21 F12
+      }
+    }
+    hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, ws->C0, P->Gf, P->d_goff, (int)P->groups.size(), G.t,
+                       d_out + c0 * G.t * G.t, nc);
+    MTRY(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace hommx

@@ -39,7 +39,7 @@ def test_all_golden_vectors():
         g = np.load(f)
         M = g["M"] if g["M"].size else None
         p = plan(int(g["dim"]), int(g["n"]), str(g["kind"]), flags=1)  # flags=1: force the blocked family
-        assert p.kernel == "blocked"
+        assert p.kernel in ("small_wave", "small_fused", "blocked")  # the family's route for this plane block size
         A, info = p.solve(g["coef"], M, return_info=True)
         assert np.all(info == 0)
         assert relerr(A, g["A_eff"]) < TOL, f
@@ -145,7 +145,7 @@ def test_full_size_golden_cells_default_plan(name):
     assert coef.shape == (3, 24576, 2)
     M = g["M"] if g["M"].size else None
     p = plan(3, 16, "elasticity")
-    assert p.kernel == "blocked"
+    assert p.kernel == "multifrontal"  # b = 768: nested dissection (csrc/multifrontal.hip); the plane elimination is checked below
     C, info = p.solve(coef, M, return_info=True)
     assert np.all(info == 0)
     assert relerr(C, g["A_eff"]) < 1e-7, relerr(C, g["A_eff"])
@@ -241,7 +241,7 @@ def test_2d_poisson_beyond_the_fused_family(rng, O):
     coef = np.exp(rng.uniform(np.log(0.05), np.log(5.0), size=(nc, 2 * n * n)))
     M = np.eye(2)[None] + 0.3 * rng.standard_normal((nc, 2, 2))
     p = plan(2, n, "poisson")
-    assert p.kernel == "blocked"
+    assert p.kernel == "small_wave"
     assert relerr(p.solve(coef, M), O.effective_tensor_batch("poisson", 2, n, coef, M)) < TOL
 
 

@@ -34,7 +34,7 @@ def test_linear_elasticity_2d_beam():
 
     h = mk()
     u = h.solve()
-    assert h._plan.kernel == "blocked" and np.all(h.cell_info == 0)
+    assert h._plan.kernel == "small_wave" and np.all(h.cell_info == 0)
     assert _rel(u, _twin(mk()).solve()) < 1e-9
     assert u.x.array.reshape(-1, 2)[:, 1].min() < 0
 

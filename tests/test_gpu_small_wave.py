@@ -73,7 +73,7 @@ def test_wave_kernel_matches_oracle(kind, dim, n):
     from oracle import hommx_oracle as O
 
     p = MicroCellPlan(dim, n, kind)
-    assert p.kernel == "blocked"
+    assert p.kernel == "small_wave"
     coef, M = _inputs(p, kind, dim, 5, 3)
     A, info = p.solve(coef, M, return_info=True)
     assert not info.any()
