@@ -86,13 +86,14 @@ struct SN {
 
 struct TreeBuilder {
   int dim, n, leaf_max;
+  int split_depth = 0;  // ring cuts at recursion depth <= split_depth are eliminated plane after plane (a chain of two fronts)
   std::vector<SN> sn;
   int coord(int node, int ax) const {
     for (int k = 0; k < ax; ++k) node /= n;
     return node % n;
   }
   // nested dissection of the box [lo, hi) (periodic[ax]: the box is the whole ring in that direction); returns the top supernode
-  int rec(const std::vector<int>& sel, const int* lo, const int* hi, const bool* periodic) {
+  int rec(const std::vector<int>& sel, const int* lo, const int* hi, const bool* periodic, int depth = 0) {
     if (sel.empty()) return -1;
     int size[3] = {1, 1, 1}, mx = 0;
     for (int a = 0; a < dim; ++a) {
@@ -140,9 +141,15 @@ struct TreeBuilder {
       h1[ax] = mid;
       l2[ax] = mid + 1;
     }
-    const int ca = rec(a_, l1, h1, per2), cb = rec(b_, l2, h2, per2);
-    // the two planes of a ring cut are eliminated one after the other (a chain: an s-sized inverse costs s^3, two halves a quarter of it)
+    const int ca = rec(a_, l1, h1, per2, depth + 1), cb = rec(b_, l2, h2, per2, depth + 1);
+    // The two planes of a ring cut can be eliminated one after the other (a chain of two fronts: an s-sized inverse costs s^3, two
+    // halves a quarter of it) or together.  The chain saves flops but costs one more pass over the r x r boundary matrix, and the
+    // update of a front is a rank-s update of that matrix -- memory-bound for small s: only the root (r = 0 / r = s) is split.
     int top = -1;
+    if (!sepB.empty() && depth > split_depth) {
+      sepA.insert(sepA.end(), sepB.begin(), sepB.end());
+      sepB.clear();
+    }
     if (!sepB.empty()) {
       SN s;
       s.nodes = sepB;
@@ -201,6 +208,7 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
   tb.n = n;
   tb.leaf_max = dim == 3 ? 27 : 9;
   if (const char* e = getenv("HOMMX_MF_LEAF")) tb.leaf_max = std::max(1, atoi(e));
+  if (const char* e = getenv("HOMMX_MF_SPLIT_DEPTH")) tb.split_depth = atoi(e);
   {
     std::vector<int> all(nn);
     for (int i = 0; i < nn; ++i) all[i] = i;
