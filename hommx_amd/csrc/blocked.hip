@@ -1063,12 +1063,12 @@ static int ws_reserve(BlockedWorkspace* ws, long long ncells, bool correctors) {
 // cell = 8 * (slot / T) + g % 8 keeps ALL tiles of one cell on one XCD's 4 MB L2; symmetric updates enumerate the
 // lower-triangle tiles only; an optional mirrored store (Ct) writes C^T as well, which replaces transpose passes.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool TA, bool TB, int TM, int NW>
+template <bool TA, bool TB, int TM, int NW, bool GATHER = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, double alpha, const double* __restrict__ A,
                                                     int lda, long long sA, const double* __restrict__ B, int ldb,
                                                     long long sB, double beta, double* __restrict__ C, int ldc,
                                                     long long sC, int lowerOnly, int nc, int tilesX, int tilesPerCell,
-                                                    double* Ct) {
+                                                    double* Ct, GatherC ga = GatherC()) {
   constexpr int PITCH = TM + 16;  // 2 PITCH dwords == 32 mod 64 for TM = 64 and 128: conflict-free ds_read_b64 fragments
   constexpr int WTM = TM / 2, WTN = TM / (NW / 2);  // per-wave tile: waves form a 2 x (NW / 2) grid
   constexpr int NFA = WTM / 16, NFB = WTN / 16;     // 16x16 MFMA tiles per wave, rows / columns
@@ -1170,6 +1170,55 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
       __syncthreads();
     }
   }
+  if constexpr (GATHER) {
+    // multifrontal extend-add fused into the Schur update: C_out = sum over the child slots of U_child[map(row)][map(col)] + alpha acc
+    // (valid entries of a child's update matrix are those on and below its diagonal: read through (max, min))
+    const int f = (int)(cell % ga.nf);
+    const long long mcell = cell / ga.nf;
+#pragma unroll
+    for (int a = 0; a < NFA; ++a)
+#pragma unroll
+      for (int b = 0; b < NFB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] *= alpha;
+#pragma unroll 1
+    for (int slot = 0; slot < 2; ++slot) {
+      const MfChild ch = ga.child[f * 2 + slot];
+      if (!ch.valid) continue;
+      const int32_t* dp = ga.dpos + ((long long)f * 2 + slot) * ga.rp;
+      const double* U = ga.arena + ga.nc * ch.offF + ((mcell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
+      int pc[NFB];
+#pragma unroll
+      for (int b = 0; b < NFB; ++b) {
+        const int col = n0 + wj0 + 16 * b + l15;
+        pc[b] = col < N ? dp[col] : -1;
+      }
+#pragma unroll
+      for (int a = 0; a < NFA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wi0 + 16 * a + l4 + 4 * r;
+          const int pr = row < M ? dp[row] : -1;
+          if (pr < 0) continue;
+#pragma unroll
+          for (int b = 0; b < NFB; ++b)
+            if (pc[b] >= 0) {
+              const int hi = pr > pc[b] ? pr : pc[b], lo = pr > pc[b] ? pc[b] : pr;
+              acc[a][b][r] += U[(long long)hi * ch.L + lo];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NFA; ++a)
+#pragma unroll
+      for (int b = 0; b < NFB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
+          if (row < M && col < N) C[(long long)row * ldc + col] = acc[a][b][r];
+        }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < NFA; ++a)
 #pragma unroll
@@ -1195,7 +1244,8 @@ inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + b
 }  // namespace
 
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
-          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly, double* Ct) {
+          const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly, double* Ct,
+          const GatherC* gather) {
   const int min128 = c.ws->gemm128_min;  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
   const bool big = M >= min128 && N >= min128;
   const int TM = big ? 128 : 64;
@@ -1209,11 +1259,20 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
   do {                                                                                                                      \
     if (big)                                                                                                                \
       hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 128, 8>), grid, dim3(512), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB,   \
-                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                \
+                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, GatherC());                                     \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 64, 4>), grid, dim3(256), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB,    \
-                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct);                                                \
+                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, GatherC());                                     \
   } while (0)
+  if (gather) {  // virtual C (multifrontal.hip): NN only
+    if (big)
+      hipLaunchKernelGGL((k_gemm_tile<false, false, 128, 8, true>), grid, dim3(512), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C,
+                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, *gather);
+    else
+      hipLaunchKernelGGL((k_gemm_tile<false, false, 64, 4, true>), grid, dim3(256), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C,
+                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, *gather);
+    return;
+  }
   if (!ta && !tb) HOMMX_GT(false, false);
   else if (!ta && tb) HOMMX_GT(false, true);
   else if (ta && !tb) HOMMX_GT(true, false);

@@ -49,10 +49,28 @@ struct Ctx {
   int infoDiv = 1;        // info index = batch index / infoDiv (fronts per cell in the multifrontal route)
 };
 
+// Child slot of a multifrontal front (multifrontal.hip), as the kernels see it
+struct MfChild {
+  long long offF;           // per-cell arena offset (doubles) of the child's GROUP buffer (x chunk size at launch)
+  int nf, fidx, L, sp;      // fronts in the child's group, the child's index in it, its leading dimension, its padded s
+  int valid, rb;            // rb: first border row of the child's boundary block
+};
+
+// "C is virtual": instead of beta * C the GEMM epilogue adds, for every child slot, the child's update matrix entry the unknown pair maps
+// to (the extend-add of the multifrontal method fused into the parent's Schur update).  batch b = cell * nf + front.
+struct GatherC {
+  const double* arena = nullptr;
+  long long nc = 0;             // cells in the chunk (arena offsets are per cell)
+  const MfChild* child = nullptr;   // [nf][2]
+  const int32_t* dpos = nullptr;    // [nf][2][rp] unknown of the child's boundary block a boundary unknown of this front maps to, -1: none
+  int nf = 0, rp = 0;
+};
+
 // C = alpha op(A) op(B) + beta C for every matrix of the batch (blocked.hip: k_gemm_tile, XCD-aware tiles); lowerOnly: tiles on and
 // below the diagonal only; Ct: mirrored copy of the result (may be C itself with lowerOnly)
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA, const double* B,
-          int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0, double* Ct = nullptr);
+          int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0, double* Ct = nullptr,
+          const GatherC* gather = nullptr);
 
 // in-place inverse of the SPD diagonal block [off, off + size) of every matrix of the batch (recursive Schur-complement form;
 // size a multiple of 32); `tmp`: scratch of at least size^2 / 2 doubles per matrix, batch stride c.sT

@@ -8,15 +8,21 @@
 //
 //        F = [ F11  F12 ]   s = the supernode's unknowns, r = the later-eliminated unknowns it touches (its "boundary")
 //            [ F21  F22 ]
-//        N = F11^-1 ;  F12 <- N F21^T ;  F22 <- F22 - F21 F12 (lower tiles) ;  load rows: Vr = R_s N, G_f = Vr R_s^T, R_r -= Vr F21^T
+//        N = F11^-1 ;  F12 <- N F21^T ;  F22 <- F22 - F21 F12 (lower tiles)
 //
 // with the SAME batched fp64-MFMA building blocks as the plane elimination (blocked.hip: k_gemm_tile, recursive block inverse).  All macro
 // cells share the structure, and fronts of equal shape at equal height of the elimination tree are independent, so every step is ONE
-// batched launch over (cells x fronts of that shape).  The update matrix F22 of a child is added into its parent while the parent's
-// front is WRITTEN (k_mf_build gathers: original stencil entries + the children's F22 entries, every entry written exactly once -- no
-// memset, no atomics); nodes are numbered in elimination order everywhere, so child -> parent index maps are monotone and only lower
-// triangles are ever needed.  Effective tensor: A_H = C0 - sum over fronts G_f  (= C0 - B^T K^+ B; reference forms
-// hmm.py:644-667 / 759-789 / 887-922 / 1024-1067); gauge: the last node is pinned in the root front (cell_problem.py:349-361).
+// batched launch over (cells x fronts of that shape).
+//   * The t canonical load vectors ride as a BORDER: 8 extra rows at the end of every front's boundary block (row m = load case m), so
+//     the same two GEMMs that update the boundary matrix also update the load rows and accumulate  -R_s N R_s^T  in the 8 x 8 corner; the
+//     corner travels up the tree with the update matrices and arrives at the root as  -B^T K^+ B:  A_H = C0 + corner
+//     (= C0 - B^T K^+ B; reference forms hmm.py:644-667 / 759-789 / 887-922 / 1024-1067).
+//   * Extend-add without a pass of its own: F22 of a front holds nothing but its children's update matrices (original stencil entries
+//     only ever sit in the columns a front eliminates), so it is never built -- the Schur-update GEMM reads "C" THROUGH the child -> parent
+//     index maps (GatherC epilogue of k_gemm_tile) and writes the front's update matrix once.  Only F11 / F21 (the eliminated columns)
+//     are written by k_mf_build: stencil entries + the children's entries, every entry exactly once -- no memset, no atomics.
+//   * Nodes are numbered in elimination order everywhere, so child -> parent maps are monotone and only lower triangles are ever needed.
+// Gauge: the last node is pinned in the root front (cell_problem.py:349-361).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -44,23 +50,17 @@ namespace hommx {
 // ---------------------------------------------------------------------------------------------------------------
 // plan: symbolic analysis (host) + index tables (device)
 // ---------------------------------------------------------------------------------------------------------------
-struct MfChild {            // one child slot of a front, as the build kernels see it
-  long long offF, offR;     // per-cell arena offsets (doubles) of the child's GROUP buffers (x chunk size at launch)
-  int nf, fidx, L, sp;      // fronts in the child's group, the child's index in it, its leading dimension, its padded s
-  int valid, pad;
-};
-
 struct MfGroup {
   int height = 0, ns = 0, nr = 0;   // nodes eliminated here / boundary nodes
-  int sp = 0, rp = 0, L = 0;        // padded unknown counts (sp: multiple of 32; rp: multiple of 16), L = sp + rp
+  int sp = 0, rb = 0, rp = 0, L = 0;   // padded eliminated unknowns (multiple of 32); boundary unknowns nr * bs; rb + border, padded to 16; sp + rp
   int nf = 0;                       // fronts of this shape at this height
-  int goff = 0;                     // first slot of the group in the per-front G_f array
-  long long offF = 0, offR = 0;     // per-cell arena offsets (doubles): F [nf][L][L], R [nf][16][L]
+  long long offF = 0;               // per-cell arena offset (doubles): F [nf][L][L]
   int pinpos = -1;                  // root only: local node whose unknowns are pinned (gauge)
   // device tables, [nf] x ...
   int32_t* d_nodes = nullptr;       // [nf][nloc]      global (periodic) node of local node
   int8_t* d_code = nullptr;         // [nf][nloc][ns]  stencil code of (row node i, column node j < ns), -1: no coupling
   int32_t* d_cpos = nullptr;        // [nf][2][nloc]   position of local node in child c's boundary list, -1: not there
+  int32_t* d_dpos = nullptr;        // [nf][2][rp]     unknown of child c's boundary block for boundary unknown p of this front, -1: none
   MfChild* d_child = nullptr;       // [nf][2]
 };
 
@@ -68,14 +68,15 @@ struct MfPlan {
   Geo G;
   std::vector<MfGroup> groups;      // in processing order (height ascending)
   int nfronts = 0;
-  long long arena_per_cell = 0;     // doubles: fronts + load rows, lifetimes overlapped
-  long long scratch_per_cell = 0;   // doubles: inverse scratch + Vr of the largest group
+  long long arena_per_cell = 0;     // doubles: fronts, lifetimes overlapped
+  long long scratch_per_cell = 0;   // doubles: inverse scratch of the largest group
   double flops_per_cell = 0.0;      // executed by the model s^3 + 2 s^2 r + s r^2 on the padded sizes
   // chunk buffers
   long long chunk = 0;
-  double *arena = nullptr, *scratch = nullptr, *Gf = nullptr;
-  int* d_goff = nullptr;
+  double *arena = nullptr, *scratch = nullptr;
 };
+
+constexpr int MF_BORDER = 8;  // load rows per front (t <= 6)
 
 namespace {
 
@@ -189,12 +190,11 @@ void mf_plan_destroy(MfPlan* p) {
     if (g.d_nodes) (void)hipFree(g.d_nodes);
     if (g.d_code) (void)hipFree(g.d_code);
     if (g.d_cpos) (void)hipFree(g.d_cpos);
+    if (g.d_dpos) (void)hipFree(g.d_dpos);
     if (g.d_child) (void)hipFree(g.d_child);
   }
   if (p->arena) (void)hipFree(p->arena);
   if (p->scratch) (void)hipFree(p->scratch);
-  if (p->Gf) (void)hipFree(p->Gf);
-  if (p->d_goff) (void)hipFree(p->d_goff);
   delete p;
 }
 
@@ -313,7 +313,8 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
     mg.ns = (int)s0.nodes.size();
     mg.nr = (int)s0.bnd.size();
     mg.sp = round_up(mg.ns * bs, 32);
-    mg.rp = round_up(mg.nr * bs, 16);
+    mg.rb = mg.nr * bs;
+    mg.rp = round_up(mg.rb + MF_BORDER, 16);
     mg.L = mg.sp + mg.rp;
     mg.nf = (int)members[g].size();
     expiry[t] = t;
@@ -339,14 +340,10 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
       peak = std::max(peak, off + size);
       return off;
     };
-    int goff = 0;
     for (int t = 0; t < ng; ++t) {
       MfGroup& mg = P->groups[t];
       mg.offF = place((long long)mg.nf * mg.L * mg.L, expiry[t], t);
-      mg.offR = place((long long)mg.nf * 16 * mg.L, expiry[t], t);
-      mg.goff = goff;
-      goff += mg.nf;
-      P->scratch_per_cell = std::max(P->scratch_per_cell, (long long)mg.nf * ((long long)mg.sp * mg.sp + 16ll * mg.sp));
+      P->scratch_per_cell = std::max(P->scratch_per_cell, (long long)mg.nf * mg.sp * mg.sp);
       const double s = mg.sp, r = mg.rp;
       P->flops_per_cell += mg.nf * (s * s * s + 2.0 * s * s * r + s * r * r);
     }
@@ -358,7 +355,7 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
     const int g = order[t];
     MfGroup& mg = P->groups[t];
     const int nloc = mg.ns + mg.nr;
-    std::vector<int32_t> nodes((size_t)mg.nf * nloc), cpos((size_t)mg.nf * 2 * nloc, -1);
+    std::vector<int32_t> nodes((size_t)mg.nf * nloc), cpos((size_t)mg.nf * 2 * nloc, -1), dpos((size_t)mg.nf * 2 * mg.rp, -1);
     std::vector<int8_t> code((size_t)mg.nf * nloc * mg.ns, (int8_t)-1);
     std::vector<MfChild> child((size_t)mg.nf * 2);
     for (int f = 0; f < mg.nf; ++f) {
@@ -377,16 +374,16 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
         }
       for (int slot = 0; slot < 2; ++slot) {
         MfChild& ch = child[(size_t)f * 2 + slot];
-        ch = MfChild{0, 0, 0, 0, 0, 0, 0, 0};
+        ch = MfChild{0, 0, 0, 0, 0, 0, 0};
         if (slot >= (int)s.children.size()) continue;
         const SN& cs = sn[s.children[slot]];
         const MfGroup& cg = P->groups[pos_of[cs.group]];
         ch.offF = cg.offF;
-        ch.offR = cg.offR;
         ch.nf = cg.nf;
         ch.fidx = cs.fidx;
         ch.L = cg.L;
         ch.sp = cg.sp;
+        ch.rb = cg.rb;
         ch.valid = 1;
         for (int q = 0; q < (int)cs.bnd.size(); ++q) {
           const int i = local[cs.bnd[q]];
@@ -397,6 +394,12 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
           }
           cpos[((size_t)f * 2 + slot) * nloc + i] = q;
         }
+        int32_t* dp = &dpos[((size_t)f * 2 + slot) * mg.rp];
+        for (int p = 0; p < mg.rb; ++p) {
+          const int q = cpos[((size_t)f * 2 + slot) * nloc + mg.ns + p / bs];
+          dp[p] = q < 0 ? -1 : q * bs + p % bs;
+        }
+        for (int m = 0; m < MF_BORDER; ++m) dp[mg.rb + m] = cg.rb + m;  // border row m of the child -> border row m here
       }
       if (s.children.size() > 2) {
         g_berr = "multifrontal plan: more than two children";
@@ -406,18 +409,8 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
       if (members[g][f] == nsn - 1) mg.pinpos = local[nn - 1];
       for (int i = 0; i < nloc; ++i) local[nd[i]] = -1;
     }
-    if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_child, child)) {
-      mf_plan_destroy(P);
-      return HOMMX_EHIP;
-    }
-  }
-  {
-    std::vector<int> goff;
-    for (const MfGroup& mg : P->groups) {
-      goff.push_back(mg.goff);
-      goff.push_back(mg.nf);
-    }
-    if (upload(&P->d_goff, goff)) {
+    if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_dpos, dpos) ||
+        upload(&mg.d_child, child)) {
       mf_plan_destroy(P);
       return HOMMX_EHIP;
     }
@@ -426,7 +419,7 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
     fprintf(stderr, "[hommx multifrontal] n = %d, bs = %d: %d fronts in %d groups, arena %.1f MB + scratch %.1f MB per cell, %.2f GFLOP per cell\n",
             n, bs, nsn, ng, 8e-6 * P->arena_per_cell, 8e-6 * P->scratch_per_cell, 1e-9 * P->flops_per_cell);
     for (const MfGroup& mg : P->groups)
-      fprintf(stderr, "   height %d: %3d fronts  s = %4d (%4d)  r = %4d (%4d)\n", mg.height, mg.nf, mg.ns * bs, mg.sp, mg.nr * bs, mg.rp);
+      fprintf(stderr, "   height %d: %3d fronts  s = %4d (%4d)  r = %4d (%4d)\n", mg.height, mg.nf, mg.ns * bs, mg.sp, mg.rb, mg.rp);
   }
   *out = P;
   return 0;
@@ -436,44 +429,70 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
 // kernels
 // ---------------------------------------------------------------------------------------------------------------
 struct MfGroupDev {
-  int ns, nloc, sp, L, nf;
-  long long offF, offR;   // per-cell arena offsets of this group's F and R buffers
+  int ns, nloc, sp, rb, L, nf;
+  long long offF;         // per-cell arena offset of this group's fronts
   const int32_t* nodes;
   const int8_t* code;
   const int32_t* cpos;
   const MfChild* child;
 };
 
-// The front of every (cell, front) of the group, lower triangle (F11 complete): original stencil entries of the columns eliminated
-// here + the children's update matrices.  One thread per pair of local nodes (i >= j): a BS x BS block.
+// The eliminated COLUMNS of every (cell, front) of the group -- F11 (complete) and F21 with its border rows: original stencil entries +
+// the children's update matrices (+ the canonical loads in the border rows).  One thread per (row node i or the border, column node
+// j < ns): a BS x BS block, or the MF_BORDER x BS border strip.  F22 is not built (see the header comment).
 template <int BS>
-__global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, double* __restrict__ arena, long long nc,
-                                                  int nn, int ncode, int jblocks) {
+__global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
+                                                  double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks) {
   const int tid = threadIdx.x;
   long long blk = blockIdx.x;
   const int jb = (int)(blk % jblocks);
   blk /= jblocks;
-  const int ib = (int)(blk % ((g.nloc + 3) / 4));
-  const long long batch = blk / ((g.nloc + 3) / 4);
+  const int iblocks = (g.nloc + 1 + 3) / 4;
+  const int ib = (int)(blk % iblocks);
+  const long long batch = blk / iblocks;
   const int i = ib * 4 + (tid >> 6), j = jb * 64 + (tid & 63);
-  if (i >= g.nloc || j > i) return;
+  if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) return;
   const long long cell = batch / g.nf;
   const int f = (int)(batch % g.nf);
+  const int32_t* nodes = g.nodes + (long long)f * g.nloc;
+  double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+  const int rj = j * BS;
+  if (i == g.nloc) {  // border rows: load case m against the unknowns of column node j
+    double v[MF_BORDER][BS];
+#pragma unroll
+    for (int m = 0; m < MF_BORDER; ++m)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) v[m][b] = m < t ? Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + b) * nn + nodes[j]] : 0.0;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+      const MfChild ch = g.child[f * 2 + slot];
+      if (!ch.valid) continue;
+      const int cj = g.cpos[((long long)f * 2 + slot) * g.nloc + j];
+      if (cj < 0) continue;
+      const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
+#pragma unroll
+      for (int m = 0; m < MF_BORDER; ++m)
+#pragma unroll
+        for (int b = 0; b < BS; ++b) v[m][b] += U[(long long)(ch.rb + m) * ch.L + cj * BS + b];
+    }
+#pragma unroll
+    for (int m = 0; m < MF_BORDER; ++m)
+#pragma unroll
+      for (int b = 0; b < BS; ++b) F[(long long)(g.sp + g.rb + m) * g.L + rj + b] = v[m][b];
+    return;
+  }
   double v[BS][BS];
 #pragma unroll
   for (int a = 0; a < BS; ++a)
 #pragma unroll
     for (int b = 0; b < BS; ++b) v[a][b] = 0.0;
-  const int32_t* nodes = g.nodes + (long long)f * g.nloc;
-  if (j < g.ns) {
-    const int code = g.code[((long long)f * g.nloc + i) * g.ns + j];
-    if (code >= 0) {
-      const double* Kc = Kst + ((cell * ncode + code) * BS) * BS * (long long)nn + nodes[i];
+  const int code = g.code[((long long)f * g.nloc + i) * g.ns + j];
+  if (code >= 0) {
+    const double* Kc = Kst + ((cell * ncode + code) * BS) * BS * (long long)nn + nodes[i];
 #pragma unroll
-      for (int a = 0; a < BS; ++a)
+    for (int a = 0; a < BS; ++a)
 #pragma unroll
-        for (int b = 0; b < BS; ++b) v[a][b] = Kc[((long long)a * BS + b) * nn];
-    }
+      for (int b = 0; b < BS; ++b) v[a][b] = Kc[((long long)a * BS + b) * nn];
   }
 #pragma unroll
   for (int slot = 0; slot < 2; ++slot) {
@@ -494,8 +513,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
         v[a][b] += U[(long long)(ci * BS + ra) * ch.L + cj * BS + rb];
       }
   }
-  double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
-  const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS, rj = j < g.ns ? j * BS : g.sp + (j - g.ns) * BS;
+  const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS;
 #pragma unroll
   for (int a = 0; a < BS; ++a)
 #pragma unroll
@@ -508,10 +526,10 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
   }
 }
 
-// padding of the eliminated block (identity) and of the boundary rows (zeros); root: the gauge node's unknowns are pinned
+// padding of the eliminated block (identity) and of the boundary rows behind the border (zeros); root: the gauge node's unknowns are pinned
 template <int BS>
-__global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int rreal, int pinpos) {
-  const int npad_s = g.sp - g.ns * BS, npad_r = (g.L - g.sp) - rreal, npin = pinpos >= 0 ? BS : 0;
+__global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int pinpos) {
+  const int npad_s = g.sp - g.ns * BS, npad_r = (g.L - g.sp) - (g.rb + MF_BORDER), npin = pinpos >= 0 ? BS : 0;
   const int lines = npad_s + npad_r + npin;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nc * g.nf * (long long)lines * g.L) return;
@@ -522,62 +540,24 @@ __global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc,
   if (line < npad_s || line >= npad_s + npad_r) {  // a row + column of the eliminated block -> unit vector
     const int p = line < npad_s ? g.ns * BS + line : pinpos * BS + (line - npad_s - npad_r);
     if (x < g.sp) F[(long long)p * g.L + x] = x == p ? 1.0 : 0.0;
-    F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
+    if (x < g.sp + g.rb + MF_BORDER) F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
   } else {  // padding row of F21
-    const int p = g.sp + rreal + (line - npad_s);
+    const int p = g.sp + g.rb + MF_BORDER + (line - npad_s);
     if (x < g.sp) F[(long long)p * g.L + x] = 0.0;
   }
 }
 
-// load rows R[16][L] of every (cell, front): the canonical loads of the columns eliminated here + the children's updated rows
-template <int BS>
-__global__ void k_mf_build_rhs(MfGroupDev g, const double* __restrict__ Brhs, double* __restrict__ arena, long long nc, int nn, int t,
-                               int rreal, int pinpos) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nc * g.nf * 16ll * g.L) return;
-  const int x = (int)(idx % g.L);
-  const int m = (int)((idx / g.L) % 16);
-  const long long batch = idx / (16ll * g.L);
-  const long long cell = batch / g.nf;
-  const int f = (int)(batch % g.nf);
-  double v = 0.0;
-  int i = -1, a = 0;
-  if (x < g.ns * BS) {
-    i = x / BS;
-    a = x % BS;
-  } else if (x >= g.sp && x < g.sp + rreal) {
-    i = g.ns + (x - g.sp) / BS;
-    a = (x - g.sp) % BS;
-  }
-  if (i >= 0 && m < t && i != pinpos) {
-    if (i < g.ns) v = Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + a) * nn + g.nodes[(long long)f * g.nloc + i]];
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const MfChild ch = g.child[f * 2 + slot];
-      if (!ch.valid) continue;
-      const int ci = g.cpos[((long long)f * 2 + slot) * g.nloc + i];
-      if (ci < 0) continue;
-      v += arena[nc * ch.offR + (cell * ch.nf + ch.fidx) * 16ll * ch.L + (long long)m * ch.L + ch.sp + ci * BS + a];
-    }
-  }
-  arena[nc * g.offR + batch * 16ll * g.L + (long long)m * g.L + x] = v;
-}
-
-// A_H = C0 - sum over all fronts of G_f
-__global__ void k_mf_finalize(const double* __restrict__ C0, const double* __restrict__ Gf, const int* __restrict__ goff, int ngroups, int t,
+// A_H = C0 + corner of the root front's update matrix (= -B^T K^+ B, lower triangle valid)
+__global__ void k_mf_finalize(const double* __restrict__ C0, const double* __restrict__ arena, long long offF, int L, int sp, int rb, int t,
                               double* __restrict__ out, long long nc) {
   const int tt = t * t;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nc * tt) return;
   const long long cell = idx / tt;
   const int m = (int)(idx % tt) / t, q = (int)(idx % tt) % t;
-  double acc = 0.0;
-  for (int g = 0; g < ngroups; ++g) {
-    const int off = goff[2 * g], nf = goff[2 * g + 1];
-    const double* p = Gf + (nc * off + cell * nf) * 256ll + m * 16 + q;
-    for (int f = 0; f < nf; ++f) acc += p[f * 256ll];
-  }
-  out[idx] = C0[idx] - acc;
+  const int hi = m > q ? m : q, lo = m > q ? q : m;
+  const double* F = arena + nc * offF + cell * (long long)L * L;
+  out[idx] = C0[idx] + F[(long long)(sp + rb + hi) * L + sp + rb + lo];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -596,20 +576,19 @@ static int mf_reserve(BlockedWorkspace* ws, long long ncells) {
   }
   if (ws->budget_gb_env > 0.0) budget_gb = ws->budget_gb_env;
   const long long stencil = (long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36;
-  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + 256ll * P->nfronts + stencil);
+  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + stencil);
   long long chunk = (long long)(budget_gb * 1e9) / per_cell;
   if (chunk < 1) chunk = 1;
   if (chunk > 4096) chunk = 4096;
   if (chunk > ncells) chunk = ncells;
   if (chunk <= P->chunk) return 0;
-  for (double** p : {&P->arena, &P->scratch, &P->Gf, &ws->Kst, &ws->Brhs, &ws->C0}) {
+  for (double** p : {&P->arena, &P->scratch, &ws->Kst, &ws->Brhs, &ws->C0}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   P->chunk = 0;
   MTRY(hipMalloc(&P->arena, 8ll * chunk * P->arena_per_cell));
   MTRY(hipMalloc(&P->scratch, 8ll * chunk * P->scratch_per_cell));
-  MTRY(hipMalloc(&P->Gf, 8ll * chunk * 256 * P->nfronts));
   MTRY(hipMalloc(&ws->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
   MTRY(hipMalloc(&ws->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
   MTRY(hipMalloc(&ws->C0, 8ll * chunk * 36));
@@ -638,51 +617,48 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
     for (const MfGroup& mg : P->groups) {
       ++gi;
       const long long nb = nc * mg.nf;  // matrices in this batch
-      MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.L, mg.nf, mg.offF, mg.offR, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
-      const int jblocks = (gd.nloc + 63) / 64;
-      const long long bblocks = nb * ((gd.nloc + 3) / 4) * jblocks;
+      MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
+      const int jblocks = (mg.ns + 63) / 64;
+      const long long bblocks = nb * ((gd.nloc + 1 + 3) / 4) * jblocks;
       if (bblocks > 0x7fffffffll) {
         g_berr = "multifrontal: build grid too large";
         return HOMMX_EINVAL;
       }
-      const int rreal = mg.nr * bs;
-      const int lines = (mg.sp - mg.ns * bs) + (mg.rp - rreal) + (mg.pinpos >= 0 ? bs : 0);
-#define HOMMX_MF_K(BS_)                                                                                                                        \
-  do {                                                                                                                                         \
-    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)bblocks), dim3(256), 0, st, gd, ws->Kst, P->arena, nc, G.nn, G.ncode, jblocks);          \
-    if (lines > 0)                                                                                                                             \
-      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3(nblk(nb * (long long)lines * mg.L)), dim3(256), 0, st, gd, P->arena, nc, rreal, mg.pinpos);       \
-    hipLaunchKernelGGL((k_mf_build_rhs<BS_>), dim3(nblk(nb * 16ll * mg.L)), dim3(256), 0, st, gd, ws->Brhs, P->arena, nc, G.nn, G.t, rreal,     \
-                       mg.pinpos);                                                                                                             \
+      const int lines = (mg.sp - mg.ns * bs) + (mg.rp - mg.rb - MF_BORDER) + (mg.pinpos >= 0 ? bs : 0);
+#define HOMMX_MF_K(BS_)                                                                                                                   \
+  do {                                                                                                                                    \
+    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)bblocks), dim3(256), 0, st, gd, ws->Kst, ws->Brhs, P->arena, nc, G.nn, G.ncode, G.t, \
+                       jblocks);                                                                                                          \
+    if (lines > 0)                                                                                                                        \
+      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3(nblk(nb * (long long)lines * mg.L)), dim3(256), 0, st, gd, P->arena, nc, mg.pinpos);         \
   } while (0)
       if (bs == 1) HOMMX_MF_K(1);
       else if (bs == 2) HOMMX_MF_K(2);
       else HOMMX_MF_K(3);
 #undef HOMMX_MF_K
       double* F = P->arena + nc * mg.offF;
-      double* R = P->arena + nc * mg.offR;
-      const long long sF = (long long)mg.L * mg.L, sR = 16ll * mg.L;
-      double* tmp = P->scratch;                                   // inverse scratch: sp^2 per matrix
-      double* Vr = P->scratch + nb * (long long)mg.sp * mg.sp;    // 16 x sp per matrix
-      double* Gg = P->Gf + nc * mg.goff * 256ll;
+      const long long sF = (long long)mg.L * mg.L;
       Ctx c{ws, nb, st, d_info ? d_info + c0 : nullptr, gi};
       c.ld = mg.L;
       c.sS = sF;
       c.sT = (long long)mg.sp * mg.sp;
       c.infoDiv = mg.nf;
-      invert(c, F, 0, mg.sp, tmp);                                                                               // F11 <- N = F11^-1
-      gemm(c, false, false, 16, mg.sp, mg.sp, 1.0, R, mg.L, sR, F, mg.L, sF, 0.0, Vr, mg.sp, 16ll * mg.sp);      // Vr = R_s N
-      gemm(c, false, true, 16, 16, mg.sp, 1.0, Vr, mg.sp, 16ll * mg.sp, R, mg.L, sR, 0.0, Gg, 16, 256);          // G_f = Vr R_s^T
-      if (mg.rp > 0) {
-        double* F21 = F + (long long)mg.sp * mg.L;
-        double* F12 = F + mg.sp;
-        double* F22 = F21 + mg.sp;
-        gemm(c, false, true, 16, mg.rp, mg.sp, -1.0, Vr, mg.sp, 16ll * mg.sp, F21, mg.L, sF, 1.0, R + mg.sp, mg.L, sR);   // R_r -= Vr F21^T
-        gemm(c, false, true, mg.sp, mg.rp, mg.sp, 1.0, F, mg.L, sF, F21, mg.L, sF, 0.0, F12, mg.L, sF);                   // F12 = N F21^T
-        gemm(c, false, false, mg.rp, mg.rp, mg.sp, -1.0, F21, mg.L, sF, F12, mg.L, sF, 1.0, F22, mg.L, sF, 1);           // F22 -= F21 F12
-      }
+      invert(c, F, 0, mg.sp, P->scratch);                                                                        // F11 <- N = F11^-1
+      double* F21 = F + (long long)mg.sp * mg.L;
+      double* F12 = F + mg.sp;
+      double* F22 = F21 + mg.sp;
+      gemm(c, false, true, mg.sp, mg.rp, mg.sp, 1.0, F, mg.L, sF, F21, mg.L, sF, 0.0, F12, mg.L, sF);           // F12 = N F21^T
+      GatherC ga;
+      ga.arena = P->arena;
+      ga.nc = nc;
+      ga.child = mg.d_child;
+      ga.dpos = mg.d_dpos;
+      ga.nf = mg.nf;
+      ga.rp = mg.rp;
+      gemm(c, false, false, mg.rp, mg.rp, mg.sp, -1.0, F21, mg.L, sF, F12, mg.L, sF, 1.0, F22, mg.L, sF, 1, nullptr, &ga);  // F22 = children - F21 F12
     }
-    hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, ws->C0, P->Gf, P->d_goff, (int)P->groups.size(), G.t,
+    const MfGroup& root = P->groups.back();
+    hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, ws->C0, P->arena, root.offF, root.L, root.sp, root.rb, G.t,
                        d_out + c0 * G.t * G.t, nc);
     MTRY(hipGetLastError());
   }
