@@ -949,6 +949,8 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
   if (const char* e = getenv("HOMMX_SMALL_WAVES")) ws->small_waves = atoi(e);
   if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
+  if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
+  ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;
   if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && G.b > 64) {
     if (int rc = mf_plan_create(&ws->mf, G)) {
       delete ws;
@@ -1198,11 +1200,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wi0 + 16 * a + l4 + 4 * r;
-          const int pr = row < M ? dp[row] : -1;
+          const int pr = row < M ? dp[row + ga.rowOff] : -1;
           if (pr < 0) continue;
 #pragma unroll
           for (int b = 0; b < NFB; ++b)
-            if (pc[b] >= 0) {
+            if (pc[b] >= 0 && !(lowerOnly && n0 + wj0 + 16 * b + l15 > row)) {
               const int hi = pr > pc[b] ? pr : pc[b], lo = pr > pc[b] ? pc[b] : pr;
               acc[a][b][r] += U[(long long)hi * ch.L + lo];
             }
@@ -1215,7 +1217,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + wi0 + 16 * a + l4 + 4 * r, col = n0 + wj0 + 16 * b + l15;
-          if (row < M && col < N) C[(long long)row * ldc + col] = acc[a][b][r];
+          if (row < M && col < N && !(lowerOnly && col > row)) C[(long long)row * ldc + col] = acc[a][b][r];  // above the diagonal: never read
         }
     return;
   }
@@ -1247,7 +1249,8 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
           const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly, double* Ct,
           const GatherC* gather) {
   const int min128 = c.ws->gemm128_min;  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
-  const bool big = M >= min128 && N >= min128;
+  // a gathering update of small rank is bound by the traffic of the tiles it touches: 64-tiles waste less of the lower triangle
+  const bool big = M >= min128 && N >= min128 && !(gather && K < c.ws->mf_gather128_min_k);
   const int TM = big ? 128 : 64;
   const int tx = (N + TM - 1) / TM, ty = (M + TM - 1) / TM;
   const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;

@@ -647,7 +647,8 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       double* F21 = F + (long long)mg.sp * mg.L;
       double* F12 = F + mg.sp;
       double* F22 = F21 + mg.sp;
-      gemm(c, false, true, mg.sp, mg.rp, mg.sp, 1.0, F, mg.L, sF, F21, mg.L, sF, 0.0, F12, mg.L, sF);           // F12 = N F21^T
+      gemm(c, true, true, mg.sp, mg.rp, mg.sp, 1.0, F, mg.L, sF, F21, mg.L, sF, 0.0, F12, mg.L, sF);  // F12 = N F21^T (N symmetric: read as N^T,
+                                                                                                      //  the k-major staging path of the tile kernel)
       GatherC ga;
       ga.arena = P->arena;
       ga.nc = nc;
@@ -655,7 +656,16 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       ga.dpos = mg.d_dpos;
       ga.nf = mg.nf;
       ga.rp = mg.rp;
-      gemm(c, false, false, mg.rp, mg.rp, mg.sp, -1.0, F21, mg.L, sF, F12, mg.L, sF, 1.0, F22, mg.L, sF, 1, nullptr, &ga);  // F22 = children - F21 F12
+      // F22 = children - F21 F12, lower tiles.  When the border rows would open a tile row of their own they get a (thin) launch instead.
+      const int TMg = (mg.rp >= ws->gemm128_min && mg.sp >= ws->mf_gather128_min_k) ? 128 : 64;
+      const bool split = mg.rb >= TMg && (mg.rp + TMg - 1) / TMg > (mg.rb + TMg - 1) / TMg && !ws->mf_no_border_split;
+      const int main_n = split ? mg.rb : mg.rp;
+      gemm(c, false, false, main_n, main_n, mg.sp, -1.0, F21, mg.L, sF, F12, mg.L, sF, 1.0, F22, mg.L, sF, 1, nullptr, &ga);
+      if (split) {
+        ga.rowOff = mg.rb;
+        gemm(c, false, false, mg.rp - mg.rb, mg.rp, mg.sp, -1.0, F21 + (long long)mg.rb * mg.L, mg.L, sF, F12, mg.L, sF, 1.0,
+             F22 + (long long)mg.rb * mg.L, mg.L, sF, 0, nullptr, &ga);
+      }
     }
     const MfGroup& root = P->groups.back();
     hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, ws->C0, P->arena, root.offF, root.L, root.sp, root.rb, G.t,
