@@ -1,0 +1,127 @@
+"""Nested-dissection route of the blocked family (csrc/multifrontal.hip; -m gpu): the same micro problems as the plane elimination
+(forms /root/reference/src/hommx/hmm.py:644-667 / 759-789 / 887-922 / 1024-1067 on the periodic unit cell, cell_problem.py:38-300),
+another elimination order.  The route is chosen when the plan is created (plane block b >= HOMMX_MF_MIN_B, default 192), hence the child
+processes for the forced / disabled variants."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _child(code, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_small_meshes_against_the_oracle_every_kind():
+    """Forced onto the multifrontal route (b > 64): odd and even n, one and three unknowns per node, all four coefficient layouts, with and
+    without the stratification matrix; trees of 10 to 60 fronts, padded and unpadded front sizes."""
+    _child(f"""
+        import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        from oracle import hommx_oracle as O
+        from test_gpu_small_wave import _inputs, _oracle_args
+        def spd_inputs(p, kind, nc, seed):   # 3D matrix-valued kinds: SPD by construction (G G^T + shift), in the layout of include/hommx_hip.h
+            rng = np.random.default_rng(seed)
+            coef, M = _inputs(p, kind, 3, nc, seed)
+            if kind == "poisson_matrix":
+                G = rng.uniform(-1, 1, size=(nc, p.n_el, 3, 3))
+                A = 0.3 * G @ np.swapaxes(G, -1, -2) + 0.5 * np.eye(3)
+                coef = np.stack([A[..., i, j] for i, j in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))], axis=-1)
+            if kind == "elasticity_voigt":
+                G = rng.uniform(-1, 1, size=(nc, p.n_el, 6, 6))
+                C = 0.2 * G @ np.swapaxes(G, -1, -2) + np.diag([2.0, 2.0, 2.0, 0.5, 0.5, 0.5])
+                iu = np.triu_indices(6)
+                coef = C[..., iu[0], iu[1]]
+            return coef, M
+        for kind, dim, n in (("elasticity", 3, 5), ("elasticity", 3, 6), ("elasticity", 3, 7), ("elasticity_voigt", 3, 5), ("poisson", 3, 9),
+                             ("poisson", 3, 11), ("poisson", 3, 12), ("poisson_matrix", 3, 9), ("elasticity", 3, 8)):
+            p = MicroCellPlan(dim, n, kind)
+            assert p.kernel == "multifrontal", (kind, n, p.kernel)
+            coef, M = spd_inputs(p, kind, 4, 7)
+            A, info = p.solve(coef, M, return_info=True)
+            assert not info.any(), (kind, n, info)
+            okind, ocoef = _oracle_args(O, kind, dim, coef)
+            ref = O.effective_tensor_batch(okind, dim, n, ocoef[:2], M[:2])
+            assert np.abs(A[:2] - ref).max() <= 1e-10 * np.abs(ref).max(), (kind, n, np.abs(A[:2] - ref).max() / np.abs(ref).max())
+            A0 = p.solve(coef[:1])
+            ref0 = O.effective_tensor_batch(okind, dim, n, ocoef[:1], None)
+            assert np.abs(A0 - ref0).max() <= 1e-10 * np.abs(ref0).max()
+            assert np.abs(A - np.swapaxes(A, 1, 2)).max() <= 1e-11 * np.abs(A).max()
+        print("ok")
+    """, {"HOMMX_MF_MIN_B": "65"})
+
+
+def test_bad_cells_are_flagged_and_do_not_leak_and_chunks_do_not_change_bits():
+    """A cell with a negative coefficient fails a pivot check somewhere in the tree: its info is the (1-based) group of the failing front,
+    every other cell of the batch is untouched -- also when the batch is cut into workspace chunks (HOMMX_BLOCKED_MEM_GB)."""
+    code = f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        rng = np.random.default_rng(11)
+        p = MicroCellPlan(3, 8, "elasticity")
+        assert p.kernel == "multifrontal"
+        coef = rng.uniform(0.5, 3.0, size=(37, p.n_el, 2))
+        M = np.eye(3)[None] + 0.2 * rng.standard_normal((37, 3, 3))
+        good, info = p.solve(coef, M, return_info=True)
+        assert not info.any()
+        bad = coef.copy(); bad[5] = -1.0; bad[30, ::7] = np.nan
+        A, info = p.solve(bad, M, return_info=True)
+        assert info[5] > 0 and info[30] > 0 and (info != 0).sum() == 2, info
+        keep = info == 0
+        assert np.array_equal(A[keep], good[keep])
+        np.save(sys.argv[1], good)
+        print("ok")
+    """
+    outs = []
+    for tag, gb in (("small", "0.02"), ("default", None)):  # 1.3 MB per cell at n = 8: 0.02 GB = 15 cells per chunk
+        f = os.path.join("/tmp", f"hommx_mf_chunk_{tag}_{os.getpid()}.npy")
+        env = {"HOMMX_MF_MIN_B": "65"}
+        if gb:
+            env["HOMMX_BLOCKED_MEM_GB"] = gb
+        subprocess_code = code.replace("sys.argv[1]", repr(f))
+        _child(subprocess_code, env)
+        outs.append(np.load(f))
+        os.remove(f)
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_production_size_agrees_with_the_plane_elimination():
+    """16^3 micro cells, three unknowns per node: the two eliminations of the blocked family on the SAME cells (C4 fibre contrast 1e5 and
+    moderate random media) -- different orders of 12,288 unknowns, results equal to rounding."""
+    code = f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan, workloads as W
+        p = MicroCellPlan(3, 16, "elasticity")
+        assert p.kernel == sys.argv[2], p.kernel
+        rng = np.random.default_rng(3)
+        coef = rng.uniform(0.5, 3.0, size=(9, p.n_el, 2))
+        M = np.eye(3)[None] + 0.2 * rng.standard_normal((9, 3, 3))
+        A, info = p.solve(coef, M, return_info=True)
+        assert not info.any()
+        msh, mask, values, _ = W.c4_two_phase(cells=np.array([0, 2000, 4319]))
+        B, info = p.solve_two_phase(mask, values, None, return_info=True)
+        assert not info.any()
+        np.savez(sys.argv[1], A=A, B=B)
+        print("ok")
+    """
+    res = {}
+    for route, env in (("multifrontal", {}), ("blocked", {"HOMMX_MF_MIN_B": "0"})):
+        f = os.path.join("/tmp", f"hommx_mf_vs_blocked_{route}_{os.getpid()}.npz")
+        _child(code.replace("sys.argv[1]", repr(f)).replace("sys.argv[2]", repr(route)), env)
+        res[route] = dict(np.load(f))
+        os.remove(f)
+    for key, tol in (("A", 1e-11), ("B", 1e-7)):  # contrast 1e5 in the fibre cells: conditioning, not the method
+        a, b = res["multifrontal"][key], res["blocked"][key]
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (key, np.abs(a - b).max() / np.abs(b).max())

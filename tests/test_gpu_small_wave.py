@@ -67,13 +67,17 @@ def _oracle_args(O, kind, dim, coef):
     return kind, coef
 
 
+def _plane_block(kind, dim, n):
+    return (dim if kind.startswith("elasticity") else 1) * n ** (dim - 1)
+
+
 @pytest.mark.parametrize("kind,dim,n", CASES)
 def test_wave_kernel_matches_oracle(kind, dim, n):
     from hommx_amd import MicroCellPlan
     from oracle import hommx_oracle as O
 
     p = MicroCellPlan(dim, n, kind)
-    assert p.kernel == "small_wave"
+    assert p.kernel == ("small_wave" if _plane_block(kind, dim, n) <= 48 else "small_fused")
     coef, M = _inputs(p, kind, dim, 5, 3)
     A, info = p.solve(coef, M, return_info=True)
     assert not info.any()
