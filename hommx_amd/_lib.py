@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "hommx_plan_coef_components",
     "hommx_plan_tensor_size",
     "hommx_plan_kernel_name",
+    "hommx_plan_flops_per_solve",
     "hommx_solve_batch",
     "hommx_solve_batch_device",
     "hommx_solve_batch_correctors",
@@ -123,6 +124,8 @@ def load():
     lib.hommx_plan_coef_components.argtypes = [vp]
     lib.hommx_plan_tensor_size.restype = i32
     lib.hommx_plan_tensor_size.argtypes = [vp]
+    lib.hommx_plan_flops_per_solve.restype = C.c_double
+    lib.hommx_plan_flops_per_solve.argtypes = [vp]
     lib.hommx_plan_kernel_name.restype = C.c_char_p
     lib.hommx_plan_kernel_name.argtypes = [vp]
     lib.hommx_solve_batch.restype = C.c_int

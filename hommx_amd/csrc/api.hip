@@ -156,6 +156,14 @@ int32_t hommx_plan_kind(const hommx_plan* p) { return p ? p->desc.kind : -1; }
 int64_t hommx_plan_num_elements(const hommx_plan* p) { return p ? p->n_el : 0; }
 int32_t hommx_plan_coef_components(const hommx_plan* p) { return p ? p->n_comp : 0; }
 int32_t hommx_plan_tensor_size(const hommx_plan* p) { return p ? p->t : 0; }
+double hommx_plan_flops_per_solve(const hommx_plan* p) {
+  if (!p) return 0.0;
+  if (p->family == FAM_FUSED2D) {
+    const double n = p->desc.n_micro;
+    return (6.0 * (n - 1) + 2.0) * n * n * n;
+  }
+  return hommx::blocked_flops_per_cell(p->ws);
+}
 const char* hommx_plan_kernel_name(const hommx_plan* p) {
   if (!p) return "";
   return p->family == FAM_FUSED2D ? "fused2d" : hommx::blocked_route_name(p->ws);

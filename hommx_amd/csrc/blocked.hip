@@ -967,6 +967,13 @@ const char* blocked_route_name(const BlockedWorkspace* ws) {
   return ws->mf ? "multifrontal" : "blocked";
 }
 
+double blocked_flops_per_cell(const BlockedWorkspace* ws) {
+  if (!ws) return 0.0;
+  if (ws->mf) return mf_flops_per_cell(ws->mf);
+  const double b = ws->G.b;
+  return (6.0 * (ws->G.n - 1) + 2.0) * b * b * b;
+}
+
 static void ws_free_main(BlockedWorkspace* ws) {
   double** ptrs[] = {&ws->Kst, &ws->Brhs, &ws->C0, &ws->S, &ws->W, &ws->Sl, &ws->V, &ws->X, &ws->T, &ws->R, &ws->Rl, &ws->Vr, &ws->Gm};
   for (auto p : ptrs) {

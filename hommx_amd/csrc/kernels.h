@@ -61,4 +61,7 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
 const char* blocked_last_error();
 // "small_wave" (b <= 48), "small_fused" (48 < b <= 64) or "blocked": the route blocked_solve takes for effective tensors
 const char* blocked_route_name(const BlockedWorkspace* ws);
+// dense flops one micro-cell solve executes on this route, by the route's own model (multifrontal: sum over the fronts of
+// s^3 + 2 s^2 r + s r^2 on the padded sizes; plane elimination: (6 (n - 1) + 2) b^3)
+double blocked_flops_per_cell(const BlockedWorkspace* ws);
 }  // namespace hommx

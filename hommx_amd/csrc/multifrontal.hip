@@ -184,6 +184,8 @@ int upload(T** dst, const std::vector<T>& src) {
 
 }  // namespace
 
+double mf_flops_per_cell(const MfPlan* p) { return p ? p->flops_per_cell : 0.0; }
+
 void mf_plan_destroy(MfPlan* p) {
   if (!p) return;
   for (MfGroup& g : p->groups) {

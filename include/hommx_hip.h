@@ -87,6 +87,9 @@ int64_t hommx_plan_num_elements(const hommx_plan* plan);
 int32_t hommx_plan_coef_components(const hommx_plan* plan);
 int32_t hommx_plan_tensor_size(const hommx_plan* plan);
 const char* hommx_plan_kernel_name(const hommx_plan* plan);
+/* Dense flops ONE micro-cell solve executes on the plan's route, by the route's own model: block-cyclic plane
+ * elimination (6 (n-1) + 2) b^3; multifrontal: sum over the fronts of s^3 + 2 s^2 r + s r^2 on the padded front sizes. */
+double hommx_plan_flops_per_solve(const hommx_plan* plan);
 
 /*
  * Solve a batch of macro cells (host pointers; the call copies in, runs, copies out, synchronises).
