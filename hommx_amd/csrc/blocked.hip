@@ -948,6 +948,9 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   ws->split64 = getenv("HOMMX_NO_SPLIT64") == nullptr;
   ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
   if (const char* e = getenv("HOMMX_SMALL_WAVES")) ws->small_waves = atoi(e);
+  // route: nested dissection (multifrontal.hip) where it beats the plane elimination (profiles/r03_kinds_routes.txt) -- three unknowns
+  // per node from b = 96 (3D elasticity n >= 6), scalar 3D problems from n = 20, 2D from b = 128 (elasticity) / 192 (scalar)
+  ws->mf_min_b = G.dim == 3 ? (G.bs >= 2 ? 96 : 400) : (G.bs >= 2 ? 128 : 192);
   if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
   if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
   ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;
@@ -1182,8 +1185,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
   if constexpr (GATHER) {
     // multifrontal extend-add fused into the Schur update: C_out = sum over the child slots of U_child[map(row)][map(col)] + alpha acc
     // (valid entries of a child's update matrix are those on and below its diagonal: read through (max, min))
-    const int f = (int)(cell % ga.nf);
-    const long long mcell = cell / ga.nf;
+    const int f = (int)((cell + ga.batch0) % ga.nf);
+    const long long mcell = (cell + ga.batch0) / ga.nf;
 #pragma unroll
     for (int a = 0; a < NFA; ++a)
 #pragma unroll
@@ -1262,6 +1265,24 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
   const int tx = (N + TM - 1) / TM, ty = (M + TM - 1) / TM;
   const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;
   const long long groups = (c.nc + 7) / 8;
+  {  // a launch holds at most 2^32 - 1 work-items (AQL grid size): huge batches go in pieces
+    const long long max_groups = std::max(1ll, (1ll << 30) / (8ll * T * (big ? 512 : 256)));
+    if (groups > max_groups) {
+      for (long long g0 = 0; g0 < groups; g0 += max_groups) {
+        Ctx sub = c;
+        const long long b0 = g0 * 8;
+        sub.nc = std::min(c.nc - b0, max_groups * 8);
+        GatherC gs;
+        if (gather) {
+          gs = *gather;
+          gs.batch0 = gather->batch0 + b0;
+        }
+        gemm(sub, ta, tb, M, N, K, alpha, A + b0 * sA, lda, sA, B + b0 * sB, ldb, sB, beta, C + b0 * sC, ldc, sC, lowerOnly,
+             Ct ? Ct + b0 * sC : nullptr, gather ? &gs : nullptr);
+      }
+      return;
+    }
+  }
   dim3 grid((unsigned)(groups * 8 * T));
   // 128 tiles: 8 waves per workgroup (2 x 4 grid of 64 x 32 wave tiles, 110 VGPRs, 4 waves per SIMD): +2 % over 4 waves
   // of 64 x 64; 64 tiles: 4 waves of 32 x 32 (8 waves measured slower)

@@ -32,7 +32,8 @@ struct BlockedWorkspace {
   double *hS = nullptr, *hW = nullptr, *hR = nullptr, *Xa = nullptr, *Xb = nullptr, *Y = nullptr;
   // nested-dissection route (3D, large plane blocks): symbolic analysis + arena, owned by multifrontal.hip
   MfPlan* mf = nullptr;
-  int mf_min_b = 192;          // HOMMX_MF_MIN_B: smallest plane block b routed to the multifrontal elimination (0: never)
+  int mf_min_b = 192;          // smallest plane block b routed to the multifrontal elimination (set per dim / unknowns per node when the
+                               // workspace is created; HOMMX_MF_MIN_B overrides, 0: never)
   bool mf_no_border_split = false;  // HOMMX_MF_NO_BORDER_SPLIT (A/B runs)
   int mf_gather128_min_k = 256;  // HOMMX_MF_G128_MIN_K: gathering Schur updates of smaller rank take the 64 x 64 tiles
 };
@@ -66,6 +67,7 @@ struct GatherC {
   const MfChild* child = nullptr;   // [nf][2]
   const int32_t* dpos = nullptr;    // [nf][2][rp] unknown of the child's boundary block a boundary unknown of this front maps to, -1: none
   int nf = 0, rp = 0;
+  long long batch0 = 0;         // batch index of matrix 0 of this launch (a huge batch is launched in pieces)
   int rowOff = 0;               // C row 0 is boundary unknown rowOff of the front (the border rows are updated by a launch of their own)
 };
 

@@ -444,16 +444,19 @@ struct MfGroupDev {
 // j < ns): a BS x BS block, or the MF_BORDER x BS border strip.  F22 is not built (see the header comment).
 template <int BS>
 __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
-                                                  double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks) {
+                                                  double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks,
+                                                  long long nblocks) {
   const int tid = threadIdx.x;
-  long long blk = blockIdx.x;
+  const int iblocks = (g.nloc + 1 + 3) / 4;
+  // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches walk the block index with a grid stride
+  for (long long blk0 = blockIdx.x; blk0 < nblocks; blk0 += gridDim.x) {
+  long long blk = blk0;
   const int jb = (int)(blk % jblocks);
   blk /= jblocks;
-  const int iblocks = (g.nloc + 1 + 3) / 4;
   const int ib = (int)(blk % iblocks);
   const long long batch = blk / iblocks;
   const int i = ib * 4 + (tid >> 6), j = jb * 64 + (tid & 63);
-  if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) return;
+  if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) continue;
   const long long cell = batch / g.nf;
   const int f = (int)(batch % g.nf);
   const int32_t* nodes = g.nodes + (long long)f * g.nloc;
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
     for (int m = 0; m < MF_BORDER; ++m)
 #pragma unroll
       for (int b = 0; b < BS; ++b) F[(long long)(g.sp + g.rb + m) * g.L + rj + b] = v[m][b];
-    return;
+    continue;
   }
   double v[BS][BS];
 #pragma unroll
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
 #pragma unroll
       for (int b = 0; b < BS; ++b) F[(long long)(rj + b) * g.L + ri + a] = v[a][b];
   }
+  }
 }
 
 // padding of the eliminated block (identity) and of the boundary rows behind the border (zeros); root: the gauge node's unknowns are pinned
@@ -533,8 +537,8 @@ template <int BS>
 __global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int pinpos) {
   const int npad_s = g.sp - g.ns * BS, npad_r = (g.L - g.sp) - (g.rb + MF_BORDER), npin = pinpos >= 0 ? BS : 0;
   const int lines = npad_s + npad_r + npin;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nc * g.nf * (long long)lines * g.L) return;
+  const long long total = nc * g.nf * (long long)lines * g.L;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
   const int x = (int)(idx % g.L);
   const int line = (int)((idx / g.L) % lines);
   const long long batch = idx / ((long long)g.L * lines);
@@ -546,6 +550,7 @@ __global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc,
   } else {  // padding row of F21
     const int p = g.sp + g.rb + MF_BORDER + (line - npad_s);
     if (x < g.sp) F[(long long)p * g.L + x] = 0.0;
+  }
   }
 }
 
@@ -622,17 +627,15 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
       const int jblocks = (mg.ns + 63) / 64;
       const long long bblocks = nb * ((gd.nloc + 1 + 3) / 4) * jblocks;
-      if (bblocks > 0x7fffffffll) {
-        g_berr = "multifrontal: build grid too large";
-        return HOMMX_EINVAL;
-      }
+      const long long max_blocks = 1ll << 22;  // x 256 threads = 2^30 work-items per launch (the AQL limit is 2^32 - 1); grid-stride beyond
       const int lines = (mg.sp - mg.ns * bs) + (mg.rp - mg.rb - MF_BORDER) + (mg.pinpos >= 0 ? bs : 0);
 #define HOMMX_MF_K(BS_)                                                                                                                   \
   do {                                                                                                                                    \
-    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)bblocks), dim3(256), 0, st, gd, ws->Kst, ws->Brhs, P->arena, nc, G.nn, G.ncode, G.t, \
-                       jblocks);                                                                                                          \
+    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)std::min(bblocks, max_blocks)), dim3(256), 0, st, gd, ws->Kst, ws->Brhs, P->arena, \
+                       nc, G.nn, G.ncode, G.t, jblocks, bblocks);                                                                         \
     if (lines > 0)                                                                                                                        \
-      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3(nblk(nb * (long long)lines * mg.L)), dim3(256), 0, st, gd, P->arena, nc, mg.pinpos);         \
+      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min((nb * (long long)lines * mg.L + 255) / 256, max_blocks)), dim3(256), 0,  \
+                         st, gd, P->arena, nc, mg.pinpos);                                                                                \
   } while (0)
       if (bs == 1) HOMMX_MF_K(1);
       else if (bs == 2) HOMMX_MF_K(2);
