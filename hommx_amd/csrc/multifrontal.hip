@@ -70,13 +70,21 @@ struct MfPlan {
   int nfronts = 0;
   long long arena_per_cell = 0;     // doubles: fronts, lifetimes overlapped
   long long scratch_per_cell = 0;   // doubles: inverse scratch of the largest group
-  double flops_per_cell = 0.0;      // executed by the model s^3 + 2 s^2 r + s r^2 on the padded sizes
+  double flops_per_cell = 0.0;      // executed dense flops by the model of mf_solve (staged elimination + Schur update) on the padded sizes
+  int stage = 192;                  // HOMMX_MF_STAGE: unknowns per elimination stage inside a front (0: one stage)
   // chunk buffers
   long long chunk = 0;
   double *arena = nullptr, *scratch = nullptr;
 };
 
 constexpr int MF_BORDER = 8;  // load rows per front (t <= 6)
+
+// stages of the elimination inside one front (mf_solve): about `stage` unknowns each, multiples of 32
+static inline int mf_stages(int sp, int stage) { return (stage <= 0 || sp < 2 * stage - 64) ? 1 : (sp + stage - 1) / stage; }
+static inline int mf_stage_size(int sp, int nst, int i) {
+  const int base = (sp / 32) / nst, extra = (sp / 32) % nst;  // 32-blocks per stage; the first `extra` stages take one more
+  return 32 * (base + (i < extra ? 1 : 0));
+}
 
 namespace {
 
@@ -211,6 +219,7 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
   tb.leaf_max = dim == 3 ? 27 : 9;
   if (const char* e = getenv("HOMMX_MF_LEAF")) tb.leaf_max = std::max(1, atoi(e));
   if (const char* e = getenv("HOMMX_MF_SPLIT_DEPTH")) tb.split_depth = atoi(e);
+  if (const char* e = getenv("HOMMX_MF_STAGE")) P->stage = atoi(e);
   {
     std::vector<int> all(nn);
     for (int i = 0; i < nn; ++i) all[i] = i;
@@ -346,8 +355,17 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
       MfGroup& mg = P->groups[t];
       mg.offF = place((long long)mg.nf * mg.L * mg.L, expiry[t], t);
       P->scratch_per_cell = std::max(P->scratch_per_cell, (long long)mg.nf * mg.sp * mg.sp);
-      const double s = mg.sp, r = mg.rp;
-      P->flops_per_cell += mg.nf * (s * s * s + 2.0 * s * s * r + s * r * r);
+      {  // inverse of a stage si^3, X_i 2 si^2 below, column update 2 below rem si, Schur update s r^2 (lower tiles)
+        const int nst = mf_stages(mg.sp, P->stage);
+        double f = (double)mg.sp * mg.rp * mg.rp;
+        int off = 0;
+        for (int i = 0; i < nst; ++i) {
+          const double si = mf_stage_size(mg.sp, nst, i), below = mg.L - (off + si), rem = mg.sp - (off + si);
+          f += si * si * si + 2.0 * si * si * below + 2.0 * below * rem * si;
+          off += (int)si;
+        }
+        P->flops_per_cell += mg.nf * f;
+      }
     }
     P->arena_per_cell = peak;
   }
@@ -648,12 +666,31 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       c.sS = sF;
       c.sT = (long long)mg.sp * mg.sp;
       c.infoDiv = mg.nf;
-      invert(c, F, 0, mg.sp, P->scratch);                                                                        // F11 <- N = F11^-1
+      // Elimination of the s unknowns in STAGES of about `stage` unknowns (one stage for small fronts): stage i inverts its diagonal
+      // block, N_i, forms X_i = N_i E_i^T for every row below it (E_i: the rows below, columns of the stage) into the free upper part
+      // of the front, and updates the not yet eliminated COLUMNS only.  After the last stage the rows of F12 hold [X_1; X_2; ...]
+      // restricted to the boundary columns and F21 holds the updated [E_1 E_2' ...]: the Schur update below is one product of rank s
+      // all the same, but the work in front of it drops from s^3 + 2 s^2 r to about 0.75 s^3 + 1.5 s^2 r (two stages).
       double* F21 = F + (long long)mg.sp * mg.L;
       double* F12 = F + mg.sp;
       double* F22 = F21 + mg.sp;
-      gemm(c, true, true, mg.sp, mg.rp, mg.sp, 1.0, F, mg.L, sF, F21, mg.L, sF, 0.0, F12, mg.L, sF);  // F12 = N F21^T (N symmetric: read as N^T,
-                                                                                                      //  the k-major staging path of the tile kernel)
+      {
+        const int nst = mf_stages(mg.sp, P->stage);
+        int off = 0;
+        for (int i = 0; i < nst; ++i) {
+          const int si = mf_stage_size(mg.sp, nst, i);
+          invert(c, F, off, si, P->scratch);                                                     // N_i
+          const int below = mg.L - (off + si), rem = mg.sp - (off + si);
+          double* Ni = F + (long long)off * mg.L + off;
+          double* Ei = F + (long long)(off + si) * mg.L + off;       // rows below the stage, its columns
+          double* Xi = F + (long long)off * mg.L + off + si;         // si x below, in the upper part of the front
+          gemm(c, true, true, si, below, si, 1.0, Ni, mg.L, sF, Ei, mg.L, sF, 0.0, Xi, mg.L, sF);   // X_i = N_i E_i^T (N_i symmetric: read as its
+                                                                                                   //  transpose, the k-major staging path)
+          if (rem > 0)                                                                            // columns still to eliminate -= E_i X_i
+            gemm(c, false, false, below, rem, si, -1.0, Ei, mg.L, sF, Xi, mg.L, sF, 1.0, F + (long long)(off + si) * mg.L + off + si, mg.L, sF);
+          off += si;
+        }
+      }
       GatherC ga;
       ga.arena = P->arena;
       ga.nc = nc;

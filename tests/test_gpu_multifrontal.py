@@ -21,9 +21,11 @@ def _child(code, env_extra, timeout=900):
     return r.stdout
 
 
-def test_small_meshes_against_the_oracle_every_kind():
+@pytest.mark.parametrize("stage", ["352", "64"])
+def test_small_meshes_against_the_oracle_every_kind(stage):
     """Forced onto the multifrontal route (b > 64): odd and even n, one and three unknowns per node, all four coefficient layouts, with and
-    without the stratification matrix; trees of 10 to 60 fronts, padded and unpadded front sizes."""
+    without the stratification matrix; trees of 10 to 60 fronts, padded and unpadded front sizes.  HOMMX_MF_STAGE = 64: fronts of 64 and
+    more eliminated unknowns go through the staged elimination (two to five stages on these meshes) that production sizes use."""
     _child(f"""
         import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
         import numpy as np
@@ -58,7 +60,7 @@ def test_small_meshes_against_the_oracle_every_kind():
             assert np.abs(A0 - ref0).max() <= 1e-10 * np.abs(ref0).max()
             assert np.abs(A - np.swapaxes(A, 1, 2)).max() <= 1e-11 * np.abs(A).max()
         print("ok")
-    """, {"HOMMX_MF_MIN_B": "65"})
+    """, {"HOMMX_MF_MIN_B": "65", "HOMMX_MF_STAGE": stage})
 
 
 def test_bad_cells_are_flagged_and_do_not_leak_and_chunks_do_not_change_bits():
