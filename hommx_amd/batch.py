@@ -135,8 +135,9 @@ class MicroCellPlan:
             raise ValueError(f"weights must have shape ({nq},)")
         params = np.ascontiguousarray(params, dtype=np.float64)
         nc = params.shape[0]
-        if params.shape != (nc, 2):
-            raise ValueError(f"params has shape {params.shape}; expected ({nc}, 2)")
+        want = (nc, 2) if self.n_comp == 1 else (nc, self.n_comp, 2)
+        if params.shape != want:
+            raise ValueError(f"params has shape {params.shape}; expected {want}")
         Mp = None
         if M is not None:
             M = np.ascontiguousarray(M, dtype=np.float64)

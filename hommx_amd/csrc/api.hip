@@ -316,7 +316,10 @@ int hommx_solve_batch_separable_device(hommx_plan* p, int64_t n_cells, int32_t f
   if (!p) return fail(HOMMX_EINVAL, "null plan");
   if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
   if (n_cells == 0) return HOMMX_OK;
-  if (p->desc.kind != HOMMX_KIND_POISSON_SCALAR) return fail(HOMMX_EINVAL, "separable samplers are defined for the scalar Poisson kind");
+  if (p->desc.kind != HOMMX_KIND_POISSON_SCALAR && p->desc.kind != HOMMX_KIND_ELASTICITY_ISO)
+    return fail(HOMMX_EINVAL, "separable samplers are defined for the scalar Poisson and the isotropic elasticity kinds");
+  if (p->desc.kind == HOMMX_KIND_ELASTICITY_ISO && family != HOMMX_SAMPLER_AFFINE)
+    return fail(HOMMX_EINVAL, "the isotropic elasticity kind takes the affine sampler only ((lambda, mu) = a + b g)");
   if (family != HOMMX_SAMPLER_AFFINE && family != HOMMX_SAMPLER_RECIPROCAL) return fail(HOMMX_EINVAL, "unknown sampler family %d", family);
   if (!d_table || !d_params || !d_A_eff) return fail(HOMMX_EINVAL, "null table / params / A_eff");
   if (family == HOMMX_SAMPLER_RECIPROCAL && (n_q < 1 || !d_weights)) return fail(HOMMX_EINVAL, "reciprocal sampler needs n_q >= 1 and weights");
@@ -333,7 +336,7 @@ int hommx_solve_batch_separable_device(hommx_plan* p, int64_t n_cells, int32_t f
     return HOMMX_OK;
   }
   // blocked family: expand on the device, chunk by chunk of at most 1 GiB of element stream
-  const int64_t per = p->n_el;
+  const int64_t per = p->n_el * p->n_comp;
   int64_t chunk = (int64_t)((1ll << 27) / (per > 0 ? per : 1));
   if (chunk < 1) chunk = 1;
   if (chunk > n_cells) chunk = n_cells;
@@ -347,7 +350,7 @@ int hommx_solve_batch_separable_device(hommx_plan* p, int64_t n_cells, int32_t f
   const int d = p->desc.dim, t = p->t;
   for (int64_t c0 = 0; c0 < n_cells; c0 += chunk) {
     const int64_t nc = (n_cells - c0 < chunk) ? n_cells - c0 : chunk;
-    HIP_TRY(hommx::launch_expand_separable(src, d_params + 2 * c0, p->d_expand, p->n_el, nc, st));
+    HIP_TRY(hommx::launch_expand_separable(src, d_params + 2 * p->n_comp * c0, p->d_expand, p->n_el, p->n_comp, nc, st));
     int rc = hommx::blocked_solve(p->ws, nc, p->d_expand, d_M ? d_M + c0 * d * d : nullptr, d_A_eff + c0 * t * t,
                                   d_info ? d_info + c0 : nullptr, st);
     if (rc != 0) return fail(rc, "blocked path: %s", hommx::blocked_last_error());
@@ -368,7 +371,7 @@ int hommx_solve_batch_separable(hommx_plan* p, int64_t n_cells, int32_t family, 
   const int64_t ntab = p->n_el * (family == HOMMX_SAMPLER_AFFINE ? 1 : n_q);
   const bool has_w = weights && n_q > 0;
   if (int rc = grow(p->st_table, sizeof(double) * ntab)) return rc;
-  if (int rc = grow(p->st_values, sizeof(double) * n_cells * 2)) return rc;
+  if (int rc = grow(p->st_values, sizeof(double) * n_cells * 2 * p->n_comp)) return rc;
   if (int rc = grow(p->st_out, sizeof(double) * n_cells * t * t)) return rc;
   if (int rc = grow(p->st_info, sizeof(int32_t) * n_cells)) return rc;
   if (has_w)
@@ -376,7 +379,7 @@ int hommx_solve_batch_separable(hommx_plan* p, int64_t n_cells, int32_t family, 
   if (M)
     if (int rc = grow(p->st_M, sizeof(double) * n_cells * d * d)) return rc;
   HIP_TRY(hipMemcpyAsync(p->st_table.p, table, sizeof(double) * ntab, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(hipMemcpyAsync(p->st_values.p, params, sizeof(double) * n_cells * 2, hipMemcpyHostToDevice, nullptr));
+  HIP_TRY(hipMemcpyAsync(p->st_values.p, params, sizeof(double) * n_cells * 2 * p->n_comp, hipMemcpyHostToDevice, nullptr));
   if (has_w) HIP_TRY(hipMemcpyAsync(p->st_w.p, weights, sizeof(double) * n_q, hipMemcpyHostToDevice, nullptr));
   if (M) HIP_TRY(hipMemcpyAsync(p->st_M.p, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice, nullptr));
   int rc = hommx_solve_batch_separable_device(p, n_cells, family, n_q, static_cast<const double*>(p->st_table.p),

@@ -851,11 +851,12 @@ hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_
 
 // separable coefficients (kernels.h): same arithmetic, operation by operation, as the fused kernel's sampler
 __global__ void k_expand_separable(CoefSource src, const double* __restrict__ params, double* __restrict__ coef, long long n_el,
-                                   long long ncells) {
+                                   int n_comp, long long ncells) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ncells * n_el) return;
-  const long long cell = idx / n_el, el = idx % n_el;
-  const double a = params[2 * cell], b = params[2 * cell + 1];
+  if (idx >= ncells * n_el * n_comp) return;
+  const int comp = (int)(idx % n_comp);
+  const long long el = (idx / n_comp) % n_el, cell = idx / (n_comp * n_el);
+  const double a = params[(cell * n_comp + comp) * 2], b = params[(cell * n_comp + comp) * 2 + 1];  // (a, b) of this component
   const double* table = static_cast<const double*>(src.table);
   if (src.mode == COEF_AFFINE) {
     coef[idx] = add_rn(a, mul_rn(b, table[el]));
@@ -867,11 +868,11 @@ __global__ void k_expand_separable(CoefSource src, const double* __restrict__ pa
   }
 }
 
-hipError_t launch_expand_separable(CoefSource src, const double* d_params, double* d_coef, long long n_el, long long ncells,
+hipError_t launch_expand_separable(CoefSource src, const double* d_params, double* d_coef, long long n_el, int n_comp, long long ncells,
                                    hipStream_t stream) {
-  const long long work = ncells * n_el;
+  const long long work = ncells * n_el * n_comp;
   if (work <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_expand_separable, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, src, d_params, d_coef, n_el,
+  hipLaunchKernelGGL(k_expand_separable, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, src, d_params, d_coef, n_el, n_comp,
                      ncells);
   return hipGetLastError();
 }

@@ -38,8 +38,8 @@ struct CoefSource {
 hipError_t launch_poisson2d_fused(const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
                                   int n, long long ncells, hipStream_t stream, CoefSource src = CoefSource());
 
-// blocked.hip: coef[cell][el] of a separable coefficient (AFFINE / RECIPROCAL) expanded into the element stream
-hipError_t launch_expand_separable(CoefSource src, const double* d_params, double* d_coef, long long n_el, long long ncells,
+// blocked.hip: coef[cell][el][comp] of a separable coefficient (AFFINE / RECIPROCAL; params[cell][comp] = (a, b)) expanded into the element stream
+hipError_t launch_expand_separable(CoefSource src, const double* d_params, double* d_coef, long long n_el, int n_comp, long long ncells,
                                    hipStream_t stream);
 
 // blocked.hip: coef[cell][el][comp] = mask[el] ? values[cell][1][comp] : values[cell][0][comp]

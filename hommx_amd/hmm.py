@@ -127,9 +127,11 @@ class Separable:
     (``hommx_solve_batch_separable``): g is tabulated once on the micro mesh at the points of the degree-3 rule UFL would
     pick, and two numbers per macro cell cross the boundary instead of n_el samples.
 
-    ``a(x)`` / ``b(x)``: x[3, N_c] -> scalar or [N_c];  ``g(y)``: y[dim, npts] -> [npts].  The object is also a plain callable
-    ``A(x, y)``.  ``host_stream`` is the documented host equivalent of the device sampler: the same IEEE operations in the same
-    order, hence the same bits (tests/test_gpu_separable.py)."""
+    ``a(x)`` / ``b(x)``: x[3, N_c] -> scalar or [N_c];  ``g(y)``: y[dim, npts] -> [npts].  For the elasticity classes ``a`` / ``b`` return
+    ``Lame(lam, mu)`` (affine family): lambda = a.lam + b.lam g, mu = a.mu + b.mu g -- the isotropic Hooke tensor of the reference's 2D
+    beam test, lambda = 1.25, mu = 5 + 4.5 sin 2 pi y0 (test_integration_linear_elasticity.py:78-93).  The object is also a plain
+    callable ``A(x, y)``.  ``host_stream`` is the documented host equivalent of the device sampler: the same IEEE operations in the
+    same order, hence the same bits (tests/test_gpu_separable.py)."""
 
     def __init__(self, family: str, a, b, g, degree: int = 3):
         """``degree``: quadrature degree of the rule that samples g -- 3 is UFL's estimate for ONE transcendental function of
@@ -139,9 +141,15 @@ class Separable:
         self.family, self.a, self.b, self.g, self.degree = family, a, b, g, int(degree)
 
     def params(self, c: np.ndarray) -> np.ndarray:
-        """[N_c, 2] = (a, b) at the macro cell midpoints c[N_c, 3]."""
+        """[N_c, 2] = (a, b) at the macro cell midpoints c[N_c, 3]; [N_c, 2, 2] = ((a, b) of lambda, (a, b) of mu) when a / b return ``Lame``."""
         n = c.shape[0]
-        return np.stack([np.broadcast_to(np.asarray(self.a(c.T), float), (n,)), np.broadcast_to(np.asarray(self.b(c.T), float), (n,))], axis=1)
+        a, b = self.a(c.T), self.b(c.T)
+        bc = lambda v: np.broadcast_to(np.asarray(v, float), (n,))
+        if isinstance(a, Lame) or isinstance(b, Lame):
+            a = a if isinstance(a, Lame) else Lame(a, a)
+            b = b if isinstance(b, Lame) else Lame(b, b)
+            return np.stack([np.stack([bc(a.lam), bc(b.lam)], axis=1), np.stack([bc(a.mu), bc(b.mu)], axis=1)], axis=1)
+        return np.stack([bc(a), bc(b)], axis=1)
 
     def table(self, yq: np.ndarray, w: np.ndarray) -> np.ndarray:
         """yq[n_el, n_q, dim] -> what the C ABI takes: affine: element means of g [n_el]; reciprocal: g at the points [n_el, n_q]."""
@@ -155,7 +163,9 @@ class Separable:
         return gq
 
     def host_stream(self, params: np.ndarray, table: np.ndarray, w: np.ndarray) -> np.ndarray:
-        """Element means coef[N_c, n_el] exactly as the device sampler forms them."""
+        """Element means coef[N_c, n_el(, 2)] exactly as the device sampler forms them."""
+        if params.ndim == 3:  # one (a, b) pair per Lame parameter
+            return np.stack([self.host_stream(params[:, k], table, w) for k in range(params.shape[1])], axis=-1)
         a, b = params[:, 0:1], params[:, 1:2]
         if self.family == "affine":
             return a + b * table[None, :]
@@ -165,7 +175,14 @@ class Separable:
         return acc
 
     def __call__(self, x, y):
-        v = self.a(x) + self.b(x) * self.g(y)
+        a, b, g = self.a(x), self.b(x), self.g(y)
+        if isinstance(a, Lame) or isinstance(b, Lame):
+            if self.family != "affine":
+                raise ValueError("Lame-valued Separable coefficients are affine (lambda, mu = a + b g)")
+            a = a if isinstance(a, Lame) else Lame(a, a)
+            b = b if isinstance(b, Lame) else Lame(b, b)
+            return Lame(a.lam + b.lam * g, a.mu + b.mu * g)
+        v = a + b * g
         return v if self.family == "affine" else 1.0 / v
 
 
@@ -476,7 +493,7 @@ class BaseHMM(ABC):
             res = self._effective_tensors_two_phase(cells)
             if res is not None:
                 return res
-        if isinstance(self._coeff, Separable) and self._kind == "poisson":
+        if isinstance(self._coeff, Separable) and (self._kind == "poisson" or self._coeff.family == "affine"):
             res = self._effective_tensors_separable(cells)
             if res is not None:
                 return res
@@ -494,8 +511,9 @@ class BaseHMM(ABC):
         return self._ensure_plan(kind).solve(coef, M, return_info=True)
 
     def _effective_tensors_separable(self, cells: np.ndarray):
-        """Device-side sampling of a ``Separable`` coefficient: one table of g on the micro mesh + (a, b) per macro cell."""
-        plan = self._ensure_plan("poisson")
+        """Device-side sampling of a ``Separable`` coefficient: one table of g on the micro mesh + (a, b) per macro cell (per Lame
+        parameter for the elasticity classes: test_integration_linear_elasticity.py:78-93)."""
+        plan = self._ensure_plan("poisson" if self._kind == "poisson" else "elasticity")
         if not hasattr(plan, "solve_separable"):
             return None
         d = self._tdim

@@ -140,11 +140,12 @@ int hommx_solve_batch_two_phase_device(hommx_plan* plan, int64_t n_cells, const 
  * 197: 0.33 + 0.15 (sin 2 pi x0 + sin 2 pi y0); :268: 1.1 + x0 + sin 2 pi y0)  or its reciprocal  1 / (a(x) + b(x) g(y))
  * (:124-125: 1 / (2 + cos 2 pi y0)).  g is tabulated ONCE on the micro mesh at the points of the quadrature rule UFL would pick
  * (degree 3: 6 points per triangle); the kernels form the element means from (a, b) of each macro cell, so 16 bytes per cell
- * cross the boundary instead of n_el samples.  Scalar Poisson kind only.
+ * cross the boundary instead of n_el samples.  Scalar Poisson kind; isotropic elasticity kind with one (a, b) pair per Lame
+ * parameter and the same g (test_integration_linear_elasticity.py:78-93: lambda = 1.25, mu = 5 + 4.5 sin 2 pi y0).
  *
  *   family   HOMMX_SAMPLER_AFFINE      A_K = a + b * table[K]                      table[n_el] = sum_q w_q g(y_{K,q})
  *            HOMMX_SAMPLER_RECIPROCAL  A_K = sum_q weights[q] / (a + b * table[K][q])   table[n_el][n_q] = g(y_{K,q})
- *   params   [n_cells][2] = (a, b) at the macro cell midpoint c_T
+ *   params   [n_cells][n_comp][2] = (a, b) of every coefficient component at the macro cell midpoint c_T (n_comp = 1, or 2 = (lambda, mu))
  *
  * Every operation is a separately rounded IEEE-754 operation in the written order (q ascending), so a host evaluating the same
  * formula reproduces the element stream bit for bit (hommx_amd.hmm.Separable.host_stream; tests/test_gpu_separable.py).

@@ -123,7 +123,10 @@ def fine_solution_beam():
 
 def run_beam(plan_hook):
     msh = mesh.create_rectangle([(0, 0), BEAM], (40, 12))
-    A = lambda x, y: hmm.Lame(1.25, 5.0 + 4.5 * np.sin(2 * np.pi * y[0]))
+    # lambda = 1.25, mu = 5 + 4.5 sin 2 pi y0 as a Separable coefficient: sampled on the device by the GPU plan (hommx_solve_batch_separable),
+    # through the generic callable path by the oracle plan -- the same element means either way
+    A = hmm.Separable("affine", lambda x: hmm.Lame(1.25 + 0.0 * x[0], 5.0 + 0.0 * x[0]), lambda x: hmm.Lame(0.0 * x[0], 4.5 + 0.0 * x[0]),
+                      lambda y: np.sin(2 * np.pi * y[0]))
     h = plan_hook(hmm.LinearElasticityHMM(msh, A, lambda x: np.array([0.0, -G_BEAM]), mesh.create_unit_square(10, 10), EPS,
                                           petsc_options_cell_problem={"ksp_atol": 1e-9}))
     V = h.function_space

@@ -64,3 +64,33 @@ def test_separable_in_poisson_hmm_matches_callable_and_analytic():
     hr.solve()
     assert np.abs(hr.effective_tensors[:, 0, 0] - 0.5).max() < 5e-4  # P1 discretisation error at n = 32 (observed 2.2e-4)
     assert np.abs(hr.effective_tensors[:, 1, 1] - 1.0 / np.sqrt(3.0)).max() < 1e-6
+
+
+@pytest.mark.parametrize("dim,n", [(2, 10), (2, 32), (3, 6)])
+def test_separable_isotropic_elasticity_equals_host_stream_bitwise(dim, n, rng):
+    """(lambda, mu) = a(x) + b(x) g(y) per Lame parameter (the reference's 2D beam coefficient, test_integration_linear_elasticity.py:78-93):
+    device sampler == plan.solve of the stream the host forms with the same formula, on the one-wave kernel (b = 20), the LDS kernel
+    (b = 64) and the multifrontal route (3D, b = 108)."""
+    from hommx_amd import MicroCellPlan, hmm
+
+    yq, w = _tables(dim, n)
+    co = hmm.Separable("affine", lambda x: hmm.Lame(1.25 + 0.5 * x[0], 5.0 + x[1]), lambda x: hmm.Lame(0.3 * x[1], 4.5 - x[0]),
+                       lambda y: np.sin(2 * np.pi * y[0]) * np.cos(2 * np.pi * y[dim - 1]))
+    nc = 6
+    c = np.concatenate([rng.uniform(size=(nc, 2)), np.zeros((nc, 1))], axis=1)
+    params, table = co.params(c), co.table(yq, w)
+    assert params.shape == (nc, 2, 2)
+    stream = co.host_stream(params, table, w)
+    assert stream.shape == (nc, yq.shape[0], 2) and stream[..., 1].min() > 0
+    p = MicroCellPlan(dim, n, "elasticity")
+    M = np.eye(dim)[None] + 0.2 * rng.standard_normal((nc, dim, dim))
+    for MM in (None, M):
+        A, info = p.solve_separable("affine", table, w, params, MM, return_info=True)
+        assert not info.any()
+        assert np.array_equal(A, p.solve(stream, MM))
+    # the stream is what the generic callable path samples, to rounding
+    v = co(c[0], yq.reshape(-1, dim).T)
+    mu = np.tensordot(w, np.asarray(v.mu).reshape(yq.shape[:2]), axes=([0], [1]))
+    assert np.abs(stream[0, :, 1] - mu).max() < 1e-14 * np.abs(mu).max()
+    with pytest.raises(Exception):
+        p.solve_separable("reciprocal", np.ones((p.n_el, len(w))), w, params)   # Lame-valued coefficients are affine
