@@ -43,6 +43,17 @@ enum Family { FAM_FUSED2D = 0, FAM_BLOCKED = 1 };
 struct hommx_plan;
 namespace {
 template <typename B>
+int grow_pinned(B& b, size_t bytes) {
+  if (bytes <= b.cap) return HOMMX_OK;
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  HIP_TRY(hipHostMalloc(&b.p, bytes, hipHostMallocDefault));
+  b.cap = bytes;
+  return HOMMX_OK;
+}
+
+template <typename B>
 int grow(B& b, size_t bytes) {
   if (bytes <= b.cap) return HOMMX_OK;
   if (b.p) (void)hipFree(b.p);
@@ -75,6 +86,8 @@ struct hommx_plan {
     size_t cap = 0;
   };
   Buf st_mask, st_values, st_table, st_w, st_M, st_out, st_info;
+  // pinned host mirrors of the small sampler inputs / outputs: one asynchronous H2D, the kernel, one asynchronous D2H, ONE synchronisation
+  Buf pin_in, pin_out, dev_in, dev_out;
   // host-pointer entry point of the fused family: coefficient chunks stream in on s_copy while s_comp solves the previous one
   hipStream_t s_copy = nullptr, s_comp = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -136,8 +149,10 @@ int hommx_plan_destroy(hommx_plan* p) {
   if (p->d_info) hipFree(p->d_info);
   if (p->ws) hommx::blocked_workspace_destroy(p->ws);
   if (p->d_expand) hipFree(p->d_expand);
-  for (hommx_plan::Buf* b : {&p->st_mask, &p->st_values, &p->st_table, &p->st_w, &p->st_M, &p->st_out, &p->st_info})
+  for (hommx_plan::Buf* b : {&p->st_mask, &p->st_values, &p->st_table, &p->st_w, &p->st_M, &p->st_out, &p->st_info, &p->dev_in, &p->dev_out})
     if (b->p) hipFree(b->p);
+  for (hommx_plan::Buf* b : {&p->pin_in, &p->pin_out})
+    if (b->p) hipHostFree(b->p);
   if (p->s_copy) hipStreamDestroy(p->s_copy);
   if (p->s_comp) hipStreamDestroy(p->s_comp);
   for (hipEvent_t e : p->ev)
@@ -291,22 +306,32 @@ int hommx_solve_batch_two_phase(hommx_plan* p, int64_t n_cells, const uint8_t* m
   if (!mask || !values || !A_eff) return fail(HOMMX_EINVAL, "null mask / values / A_eff");
   HIP_TRY(hipSetDevice(p->desc.device));
   const int d = p->desc.dim, t = p->t;
-  // staging lives in the plan (grown on demand): no hipMalloc / hipFree per call
-  if (int rc = grow(p->st_mask, (size_t)p->n_el)) return rc;
-  if (int rc = grow(p->st_values, sizeof(double) * n_cells * 2 * p->n_comp)) return rc;
-  if (int rc = grow(p->st_out, sizeof(double) * n_cells * t * t)) return rc;
-  if (int rc = grow(p->st_info, sizeof(int32_t) * n_cells)) return rc;
-  if (M)
-    if (int rc = grow(p->st_M, sizeof(double) * n_cells * d * d)) return rc;
-  HIP_TRY(hipMemcpyAsync(p->st_mask.p, mask, p->n_el, hipMemcpyHostToDevice, nullptr));
-  HIP_TRY(hipMemcpyAsync(p->st_values.p, values, sizeof(double) * n_cells * 2 * p->n_comp, hipMemcpyHostToDevice, nullptr));
-  if (M) HIP_TRY(hipMemcpyAsync(p->st_M.p, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice, nullptr));
-  int rc = hommx_solve_batch_two_phase_device(p, n_cells, static_cast<const uint8_t*>(p->st_mask.p), static_cast<const double*>(p->st_values.p),
-                                              M ? static_cast<const double*>(p->st_M.p) : nullptr, static_cast<double*>(p->st_out.p),
-                                              static_cast<int32_t*>(p->st_info.p), nullptr);
+  // The inputs are small (a mask + two values per cell): they are packed into ONE pinned block owned by the plan and travel in one
+  // asynchronous copy; the outputs come back the same way, and the call synchronises once.  No hipMalloc / hipFree per call.
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t o_mask = 0, o_val = up((size_t)p->n_el), o_M = o_val + up(sizeof(double) * n_cells * 2 * p->n_comp);
+  const size_t in_bytes = o_M + (M ? up(sizeof(double) * n_cells * d * d) : 0);
+  const size_t o_info = up(sizeof(double) * n_cells * t * t), out_bytes = o_info + up(sizeof(int32_t) * n_cells);
+  if (int rc = grow_pinned(p->pin_in, in_bytes)) return rc;
+  if (int rc = grow_pinned(p->pin_out, out_bytes)) return rc;
+  if (int rc = grow(p->dev_in, in_bytes)) return rc;
+  if (int rc = grow(p->dev_out, out_bytes)) return rc;
+  char* hin = static_cast<char*>(p->pin_in.p);
+  char* din = static_cast<char*>(p->dev_in.p);
+  char* dout = static_cast<char*>(p->dev_out.p);
+  memcpy(hin + o_mask, mask, (size_t)p->n_el);
+  memcpy(hin + o_val, values, sizeof(double) * n_cells * 2 * p->n_comp);
+  if (M) memcpy(hin + o_M, M, sizeof(double) * n_cells * d * d);
+  HIP_TRY(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, nullptr));
+  int rc = hommx_solve_batch_two_phase_device(p, n_cells, reinterpret_cast<const uint8_t*>(din + o_mask), reinterpret_cast<const double*>(din + o_val),
+                                              M ? reinterpret_cast<const double*>(din + o_M) : nullptr, reinterpret_cast<double*>(dout),
+                                              reinterpret_cast<int32_t*>(dout + o_info), nullptr);
   if (rc != HOMMX_OK) return rc;
-  HIP_TRY(hipMemcpy(A_eff, p->st_out.p, sizeof(double) * n_cells * t * t, hipMemcpyDeviceToHost));  // default stream: after the kernel
-  if (info) HIP_TRY(hipMemcpy(info, p->st_info.p, sizeof(int32_t) * n_cells, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(p->pin_out.p, dout, out_bytes, hipMemcpyDeviceToHost, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  const char* hout = static_cast<const char*>(p->pin_out.p);
+  memcpy(A_eff, hout, sizeof(double) * n_cells * t * t);
+  if (info) memcpy(info, hout + o_info, sizeof(int32_t) * n_cells);
   return HOMMX_OK;
 }
 
