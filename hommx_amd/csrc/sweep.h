@@ -227,15 +227,10 @@ struct SweepStepBlk {
     double ur[BS], uc[BS], t[BS];
 #pragma unroll
     for (int q = 0; q < BS; q += 2) {
-#ifdef HOMMX_ABLATE_SWEEPLDS  // timing experiment only (wrong results): no LDS traffic in the sweep
-      ur[q] = s[q]; ur[q + 1] = s[q + 1];
-      uc[q] = s[BS + q]; uc[q + 1] = s[BS + q + 1];
-#else
       const double2 a = *reinterpret_cast<const double2*>(&ubuf[BS * bi + q]);
       const double2 b = *reinterpret_cast<const double2*>(&ubuf[BS * bj + q]);
       ur[q] = a.x; ur[q + 1] = a.y;
       uc[q] = b.x; uc[q + 1] = b.y;
-#endif
     }
 #pragma unroll
     for (int r = 0; r < BS; ++r) t[r] = ur[r] * pinv;  // scaled pivot-row entries at my rows (== new pivot column)
