@@ -1397,13 +1397,14 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
                                                                          // (= A11^-1 + Xm^T T^-1 Xm): lower tiles, mirrored in place
 }
 
-void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st) {
+void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st, double* Kst, double* Brhs,
+                     double* C0) {
   const Geo& G = ws->G;
   // ---- K1: the stencil row of a node (3D elasticity: of one row component of a node) in registers, written once, no memset
   {
 #define HOMMX_ASMR(D_, K_, SPLIT_)                                                                                          \
   hipLaunchKernelGGL((k_assemble_reg<D_, K_, SPLIT_>), dim3(nblk(nc * G.nn * (SPLIT_ ? D_ : 1), 128)), dim3(128), 0, st, G, coef, Mm, \
-                     ws->Kst, ws->Brhs, nc)
+                     Kst, Brhs, nc)
     if (G.dim == 2) {
       if (G.kind == 0) HOMMX_ASMR(2, 0, 0); else if (G.kind == 1) HOMMX_ASMR(2, 1, 0); else if (G.kind == 2) HOMMX_ASMR(2, 2, 0); else HOMMX_ASMR(2, 3, 0);
     } else {
@@ -1414,8 +1415,8 @@ void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm,
   {
 #define HOMMX_C0(D_, K_)                                                                                                  \
   do {                                                                                                                    \
-    if (G.n_el <= 4096) hipLaunchKernelGGL((k_c0<D_, K_, 1>), dim3(nblk(nc, 4)), dim3(256), 0, st, G, coef, ws->C0, nc);   \
-    else hipLaunchKernelGGL((k_c0<D_, K_, 4>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, ws->C0, nc);                 \
+    if (G.n_el <= 4096) hipLaunchKernelGGL((k_c0<D_, K_, 1>), dim3(nblk(nc, 4)), dim3(256), 0, st, G, coef, C0, nc);   \
+    else hipLaunchKernelGGL((k_c0<D_, K_, 4>), dim3((unsigned)nc), dim3(256), 0, st, G, coef, C0, nc);                 \
   } while (0)
     if (G.dim == 2) {
       if (G.kind == 0) HOMMX_C0(2, 0); else if (G.kind == 1) HOMMX_C0(2, 1); else if (G.kind == 2) HOMMX_C0(2, 2); else HOMMX_C0(2, 3);
@@ -1444,7 +1445,7 @@ int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, 
     Ctx c{ws, nc, st, d_info ? d_info + c0 : nullptr, 0};
     const double* coef = d_coef + c0 * G.n_el * G.ncomp;
     const double* Mm = d_M ? d_M + c0 * G.dim * G.dim : nullptr;
-    launch_assembly(ws, coef, Mm, nc, st);
+    launch_assembly(ws, coef, Mm, nc, st, ws->Kst, ws->Brhs, ws->C0);
     if (G.b <= 64 && !d_corr && ws->small_fused) {
       // small plane blocks: the whole elimination in ONE launch -- b <= 48: one wave per macro cell, matrices in registers
       // (small_wave.h); 48 < b <= 64, or HOMMX_SMALL_WAVES = 2 | 4: that many waves per cell, matrices in LDS (small_fused.h)

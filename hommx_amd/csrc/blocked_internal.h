@@ -89,7 +89,9 @@ void mf_plan_destroy(MfPlan* p);
 double mf_flops_per_cell(const MfPlan* p);
 int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
              hipStream_t st);
-// K1 of the blocked family (stencil rows, loads, C0 of `nc` cells into ws->Kst / Brhs / C0), shared by both eliminations
-void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st);
+// K1 of the blocked family (stencil rows, loads, C0 of `nc` cells into the given buffers), shared by both eliminations: each route owns
+// its buffers (a plan may serve effective tensors on one route and correctors on the other, with different chunk sizes)
+void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st, double* Kst, double* Brhs,
+                     double* C0);
 
 }  // namespace hommx

@@ -75,6 +75,7 @@ struct MfPlan {
   // chunk buffers
   long long chunk = 0;
   double *arena = nullptr, *scratch = nullptr;
+  double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;  // K1 output of this route's chunks (the plane elimination keeps its own)
 };
 
 constexpr int MF_BORDER = 8;  // load rows per front (t <= 6)
@@ -203,8 +204,8 @@ void mf_plan_destroy(MfPlan* p) {
     if (g.d_dpos) (void)hipFree(g.d_dpos);
     if (g.d_child) (void)hipFree(g.d_child);
   }
-  if (p->arena) (void)hipFree(p->arena);
-  if (p->scratch) (void)hipFree(p->scratch);
+  for (double* q : {p->arena, p->scratch, p->Kst, p->Brhs, p->C0})
+    if (q) (void)hipFree(q);
   delete p;
 }
 
@@ -607,16 +608,16 @@ static int mf_reserve(BlockedWorkspace* ws, long long ncells) {
   if (chunk > 4096) chunk = 4096;
   if (chunk > ncells) chunk = ncells;
   if (chunk <= P->chunk) return 0;
-  for (double** p : {&P->arena, &P->scratch, &ws->Kst, &ws->Brhs, &ws->C0}) {
+  for (double** p : {&P->arena, &P->scratch, &P->Kst, &P->Brhs, &P->C0}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   P->chunk = 0;
   MTRY(hipMalloc(&P->arena, 8ll * chunk * P->arena_per_cell));
   MTRY(hipMalloc(&P->scratch, 8ll * chunk * P->scratch_per_cell));
-  MTRY(hipMalloc(&ws->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
-  MTRY(hipMalloc(&ws->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
-  MTRY(hipMalloc(&ws->C0, 8ll * chunk * 36));
+  MTRY(hipMalloc(&P->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
+  MTRY(hipMalloc(&P->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
+  MTRY(hipMalloc(&P->C0, 8ll * chunk * 36));
   P->chunk = chunk;
   return 0;
 }
@@ -637,7 +638,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
   const int bs = G.bs;
   for (long long c0 = 0; c0 < ncells; c0 += step_cells) {
     const long long nc = std::min(step_cells, ncells - c0);
-    launch_assembly(ws, d_coef + c0 * G.n_el * G.ncomp, d_M ? d_M + c0 * G.dim * G.dim : nullptr, nc, st);
+    launch_assembly(ws, d_coef + c0 * G.n_el * G.ncomp, d_M ? d_M + c0 * G.dim * G.dim : nullptr, nc, st, P->Kst, P->Brhs, P->C0);
     int gi = 0;
     for (const MfGroup& mg : P->groups) {
       ++gi;
@@ -649,7 +650,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       const int lines = (mg.sp - mg.ns * bs) + (mg.rp - mg.rb - MF_BORDER) + (mg.pinpos >= 0 ? bs : 0);
 #define HOMMX_MF_K(BS_)                                                                                                                   \
   do {                                                                                                                                    \
-    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)std::min(bblocks, max_blocks)), dim3(256), 0, st, gd, ws->Kst, ws->Brhs, P->arena, \
+    hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)std::min(bblocks, max_blocks)), dim3(256), 0, st, gd, P->Kst, P->Brhs, P->arena, \
                        nc, G.nn, G.ncode, G.t, jblocks, bblocks);                                                                         \
     if (lines > 0)                                                                                                                        \
       hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min((nb * (long long)lines * mg.L + 255) / 256, max_blocks)), dim3(256), 0,  \
@@ -710,7 +711,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       }
     }
     const MfGroup& root = P->groups.back();
-    hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, ws->C0, P->arena, root.offF, root.L, root.sp, root.rb, G.t,
+    hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(nc * G.t * G.t)), dim3(256), 0, st, P->C0, P->arena, root.offF, root.L, root.sp, root.rb, G.t,
                        d_out + c0 * G.t * G.t, nc);
     MTRY(hipGetLastError());
   }

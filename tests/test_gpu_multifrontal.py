@@ -127,3 +127,21 @@ def test_production_size_agrees_with_the_plane_elimination():
     for key, tol in (("A", 1e-11), ("B", 1e-7)):  # contrast 1e5 in the fibre cells: conditioning, not the method
         a, b = res["multifrontal"][key], res["blocked"][key]
         assert np.abs(a - b).max() <= tol * np.abs(b).max(), (key, np.abs(a - b).max() / np.abs(b).max())
+
+
+def test_correctors_on_the_same_plan_do_not_disturb_the_tensors(rng):
+    """Effective tensors come from the nested-dissection route, correctors from the plane elimination (hommx_solve_batch_correctors): one
+    plan serves both, with workspaces of different chunk sizes -- interleaved calls must not see each other's buffers, and the correctors'
+    Schur form reproduces the tensors of the other route."""
+    from hommx_amd import MicroCellPlan
+
+    p = MicroCellPlan(3, 6, "elasticity")
+    assert p.kernel == "multifrontal"
+    coef = rng.uniform(0.5, 3.0, size=(40, p.n_el, 2))
+    M = np.eye(3)[None] + 0.2 * rng.standard_normal((40, 3, 3))
+    A1 = p.solve(coef, M)
+    A2, chi = p.solve(coef[:3], M[:3], return_correctors=True)   # plane elimination, 3 cells: a much smaller workspace
+    A3 = p.solve(coef, M)                                        # 40 cells on the multifrontal route again
+    assert np.array_equal(A1, A3)
+    assert np.abs(A2 - A1[:3]).max() <= 1e-11 * np.abs(A1).max()
+    assert chi.shape == (3, 6, 6**3 * 3) and np.isfinite(chi).all()
