@@ -102,7 +102,9 @@ double hommx_plan_flops_per_solve(const hommx_plan* plan);
  *   M      [n_cells][d][d] or NULL  Dtheta_transpose(c_T), M[i][j] = d theta_j / d x_i (hmm.py:741, 756-757)
  *   A_eff  [n_cells][t][t]          out: effective tensor = vol(Y)^-1 * the functional of hmm.py:652-667 /
  *                                   774-789 / 905-922 / 1050-1067 on the canonical unit gradients / strains
- *   info   [n_cells] or NULL        out: 0 ok; k>0 non-positive or NaN pivot first seen in block step k-1
+ *   info   [n_cells] or NULL        out: 0 ok; k>0 non-positive or NaN pivot first seen in block step k-1 of the plane elimination
+ *                                   (fused2d / small_* / blocked routes), or in the k-th group of fronts, counted from the leaves, of
+ *                                   the multifrontal route; the cell's tensor is then not meaningful (the reference logs and goes on)
  */
 int hommx_solve_batch(hommx_plan* plan, int64_t n_cells, const double* coef, const double* M,
                       double* A_eff, int32_t* info);
