@@ -1,5 +1,6 @@
-// multifrontal.hip -- nested-dissection (multifrontal) elimination of the periodic micro problem for LARGE plane blocks (3D, b >= 192:
-// BASELINE configurations C4 / C5, 16^3 micro cells x 3 components = 12,288 unknowns per macro cell).
+// multifrontal.hip -- nested-dissection (multifrontal) elimination of the periodic micro problem for LARGE plane blocks (3D elasticity from
+// 6^3 micro cells -- BASELINE configurations C4 / C5: 16^3 micro cells x 3 components = 12,288 unknowns per macro cell -- and large 2D
+// meshes; the thresholds are set in blocked_workspace_create from measurements).
 //
 // Why: the block-cyclic plane elimination of blocked.hip carries a dense b x b arrow through n - 1 steps, (6 (n-1) + 2) b^3 model flops
 // (41.7 GFLOP per C4 / C5 cell); a sparse Cholesky under nested dissection needs 11.3 GFLOP (profiles/fref.json).  Here the torus is
