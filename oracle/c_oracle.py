@@ -29,6 +29,8 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.hommx_oracle_poisson2d.restype = C.c_int
         lib.hommx_oracle_poisson2d.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        lib.hommx_oracle_generic.restype = C.c_int
+        lib.hommx_oracle_generic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -50,3 +52,24 @@ def effective_tensor_batch_c(n: int, coef: np.ndarray, M: np.ndarray | None = No
         raise ValueError("hommx_oracle_poisson2d: bad arguments (3 <= n <= 64)")
     effective_tensor_batch_c.threads_used = used
     return (out, info) if return_info else out
+
+
+def effective_tensor_generic_c(kind: str, dim: int, n: int, coef: np.ndarray, M: np.ndarray | None = None) -> np.ndarray:
+    """ONE cell through the element-by-element C restatement (hommx_oracle_generic): ``kind`` / ``coef`` as hommx_oracle.build_cell_problem
+    takes them -- 'poisson' with coef[n_el] or [n_el, d, d]; 'elasticity' with coef[n_el, 2] = (lambda, mu) or [n_el, d, d, d, d]."""
+    coef = np.ascontiguousarray(coef, dtype=np.float64)
+    if kind == "poisson":
+        k = 0 if coef.ndim == 1 else 1
+        t = dim
+    else:
+        k = 2 if coef.ndim == 2 else 3
+        t = dim * (dim + 1) // 2
+    Mp = None
+    if M is not None:
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        Mp = M.ctypes.data
+    out = np.empty((t, t))
+    rc = load().hommx_oracle_generic(dim, n, k, coef.ctypes.data, Mp, out.ctypes.data)
+    if rc:
+        raise ValueError("hommx_oracle_generic: bad arguments or a non-positive pivot")
+    return out
