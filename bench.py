@@ -699,6 +699,19 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
         "info_nonzero": n_bad,
         "symmetry_defect": sym,
     }
+    # HBM traffic of the route: PMC counters need their own rocprofv3 passes, so the figure comes from the committed summary of
+    # tools/profile_mf.sh (same problem size; FETCH_SIZE x 2 as the hardware guide prescribes on gfx950, + WRITE_SIZE), per solve
+    try:
+        pm = json.load(open(os.path.join(HERE, "profiles", "r03_mf_pmc_summary.json")))
+        if plan.kernel == "multifrontal" and n == 16:
+            rec["roofline"]["traffic"] = pm["hbm_bytes_per_cell_total"] * nloc
+            rec["roofline"]["traffic_per_solve"] = pm["hbm_bytes_per_cell_total"]
+            rec["roofline"]["traffic_source"] = "profiles/r03_mf_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over all kernels of the route)"
+            rec["roofline"]["traffic_algorithmic_per_solve"] = 8.0 * (6 * n**3 * 2 + 9 + 36)  # coefficient stream + M + C_H
+            rec["roofline"]["mfma_busy_fraction_gemm"] = pm["families"]["gemm_gather"]["mfma_busy_fraction_of_simd_cycles"]
+            rec["roofline"]["hbm_GBps"] = pm["hbm_bytes_per_cell_total"] * nloc / (kern_ms * 1e-3) / 1e9
+    except Exception:
+        pass
     if cpu is not None:
         rec["cpu_baseline"] = cpu
     return rec
