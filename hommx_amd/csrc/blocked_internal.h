@@ -35,7 +35,7 @@ struct BlockedWorkspace {
   int mf_min_b = 192;          // smallest plane block b routed to the multifrontal elimination (set per dim / unknowns per node when the
                                // workspace is created; HOMMX_MF_MIN_B overrides, 0: never)
   bool mf_no_border_split = false;  // HOMMX_MF_NO_BORDER_SPLIT (A/B runs)
-  int mf_gather128_min_k = 256;  // HOMMX_MF_G128_MIN_K: gathering Schur updates of smaller rank take the 64 x 64 tiles
+  int mf_gather128_min_k = 1024;  // HOMMX_MF_G128_MIN_K: gathering Schur updates of smaller rank take the 64 x 64 tiles
 };
 
 
