@@ -220,7 +220,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def spawn_ranks(gpus: int, argv: list[str]) -> int:
+def spawn_ranks(gpus: int, argv: list[str], timeout_s: float = 3000.0) -> int:
     """Start `gpus` ranks of this script as CHILD processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
     environment, exactly what torch.distributed.run would set), relay rank 0's JSON line, return non-zero if any rank
     failed.  The parent never initialises the GPU and never execs: the ranks are ordinary children."""
@@ -233,7 +233,13 @@ def spawn_ranks(gpus: int, argv: list[str]) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = kids[0].communicate()
+    try:
+        out0, _ = kids[0].communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:  # a rank that never arrives leaves the others in a collective: end them all, fail loudly
+        for k in kids:
+            k.kill()
+        print(f"[bench] ranks did not finish within {timeout_s:.0f} s: killed", file=sys.stderr)
+        return 1
     rcs = [kids[0].returncode]
     for k in kids[1:]:
         try:
