@@ -145,3 +145,35 @@ def test_correctors_on_the_same_plan_do_not_disturb_the_tensors(rng):
     assert np.array_equal(A1, A3)
     assert np.abs(A2 - A1[:3]).max() <= 1e-11 * np.abs(A1).max()
     assert chi.shape == (3, 6, 6**3 * 3) and np.isfinite(chi).all()
+
+
+def test_stratified_elasticity_solver_class_on_the_multifrontal_route():
+    """The reference's rotated-fibre example shape (LinearElasticityStratifiedHMM, examples/linear_elasticity/rotated_fibers.py:23-115,
+    README.md:171-185) with 6^3 micro cells -- plane block b = 108, the nested-dissection route -- and the two-phase device sampler:
+    final macro solution == the same class with the oracle standing in for the GPU plan (rel. L2 <= 1e-7 at fibre contrast 1e5)."""
+    from hommx_amd import fem, hmm, mesh, workloads as W
+    from test_hmm_host import with_oracle
+
+    def Dt(x):
+        x = np.asarray(x, float)
+        if x.ndim == 1:
+            return W.c5_theta_transpose(x[None, :3])[0]
+        return np.moveaxis(W.c5_theta_transpose(x.T), 0, -1)
+
+    def mk():
+        msh = mesh.create_box([(0, 0, 0), (1.0, 0.4, 0.1)], (5, 2, 1))
+        A = hmm.TwoPhase(lambda y: W.wrapped_disc(y[1], y[2]), lambda x: hmm.Lame(1.0 + 0 * x[0], 100.0 * (1.0 + x[0])),
+                         lambda x: hmm.Lame(1.0 + 0 * x[0], 0.001 + 0 * x[0]))
+        h = hmm.LinearElasticityStratifiedHMM(msh, A, lambda x: np.array([0.0, 0.0, -0.05 * 0.4**2]), mesh.create_unit_cube(6, 6, 6), 2.0**-5, Dt)
+        V = h.function_space
+        clamp = fem.locate_dofs_topological(V, 2, fem.locate_entities_boundary(msh, 2, lambda x: np.isclose(x[0], 0)))
+        h.set_boundary_conditions(fem.dirichletbc(np.zeros(3), clamp, V))
+        return h
+
+    h = mk()
+    u = h.solve()
+    assert h._plan.kernel == "multifrontal" and not h.cell_info.any()
+    ref = with_oracle(mk()).solve()
+    d = u.x.array - ref.x.array
+    assert np.linalg.norm(d) <= 1e-7 * np.linalg.norm(ref.x.array), np.linalg.norm(d) / np.linalg.norm(ref.x.array)
+    assert u.x.array.reshape(-1, 3)[:, 2].min() < 0  # the beam bends down
