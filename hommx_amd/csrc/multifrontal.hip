@@ -552,25 +552,34 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
   }
 }
 
-// padding of the eliminated block (identity) and of the boundary rows behind the border (zeros); root: the gauge node's unknowns are pinned
+// padding of the eliminated block (identity) and of the boundary rows behind the border (zeros); root: the gauge node's unknowns are pinned.
+// Work items per front, each a CONTIGUOUS run along a row (the padding columns of one row are adjacent: written as one segment, not as
+// npad stride-L column walks):  rows [0, nrow) x the npad_s padding columns | the npad_s padding rows x [0, sp) | the npad_r rows behind
+// the border x [0, sp) | (root) 2 BS pin lines.
 template <int BS>
 __global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int pinpos) {
-  const int npad_s = g.sp - g.ns * BS, npad_r = (g.L - g.sp) - (g.rb + MF_BORDER), npin = pinpos >= 0 ? BS : 0;
-  const int lines = npad_s + npad_r + npin;
-  const long long total = nc * g.nf * (long long)lines * g.L;
+  const int s0 = g.ns * BS, npad_s = g.sp - s0, nrow = g.sp + g.rb + MF_BORDER, npad_r = g.L - nrow, npin = pinpos >= 0 ? BS : 0;
+  const long long wA = (long long)nrow * npad_s, wB = (long long)npad_s * g.sp, wC = (long long)npad_r * g.sp, wD = 2ll * npin * nrow;
+  const long long per = wA + wB + wC + wD, total = nc * g.nf * per;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-  const int x = (int)(idx % g.L);
-  const int line = (int)((idx / g.L) % lines);
-  const long long batch = idx / ((long long)g.L * lines);
-  double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
-  if (line < npad_s || line >= npad_s + npad_r) {  // a row + column of the eliminated block -> unit vector
-    const int p = line < npad_s ? g.ns * BS + line : pinpos * BS + (line - npad_s - npad_r);
-    if (x < g.sp) F[(long long)p * g.L + x] = x == p ? 1.0 : 0.0;
-    if (x < g.sp + g.rb + MF_BORDER) F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
-  } else {  // padding row of F21
-    const int p = g.sp + g.rb + MF_BORDER + (line - npad_s);
-    if (x < g.sp) F[(long long)p * g.L + x] = 0.0;
-  }
+    const long long batch = idx / per;
+    long long w = idx % per;
+    double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+    if (w < wA) {  // column part of the identity padding: F[x][s0 + q], x < nrow
+      const int x = (int)(w / npad_s), p = s0 + (int)(w % npad_s);
+      F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
+    } else if ((w -= wA) < wB) {  // row part: F[s0 + q][x], x < sp
+      const int p = s0 + (int)(w / g.sp), x = (int)(w % g.sp);
+      F[(long long)p * g.L + x] = x == p ? 1.0 : 0.0;
+    } else if ((w -= wB) < wC) {  // F21 rows behind the border
+      const int p = nrow + (int)(w / g.sp), x = (int)(w % g.sp);
+      F[(long long)p * g.L + x] = 0.0;
+    } else {  // gauge: unit row and column of the pinned unknowns (the load rows lose their entry there too)
+      w -= wC;
+      const int q = (int)(w / (2 * nrow)), y = (int)(w % (2 * nrow)), p = pinpos * BS + q;
+      if (y < nrow) F[(long long)y * g.L + p] = y == p ? 1.0 : 0.0;
+      else if (y - nrow < g.sp) F[(long long)p * g.L + (y - nrow)] = (y - nrow) == p ? 1.0 : 0.0;
+    }
   }
 }
 
@@ -648,14 +657,15 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       const int jblocks = (mg.ns + 63) / 64;
       const long long bblocks = nb * ((gd.nloc + 1 + 3) / 4) * jblocks;
       const long long max_blocks = 1ll << 22;  // x 256 threads = 2^30 work-items per launch (the AQL limit is 2^32 - 1); grid-stride beyond
-      const int lines = (mg.sp - mg.ns * bs) + (mg.rp - mg.rb - MF_BORDER) + (mg.pinpos >= 0 ? bs : 0);
+      const long long pad_work = (long long)(mg.sp + mg.rb + MF_BORDER) * (mg.sp - mg.ns * bs) + (long long)(mg.sp - mg.ns * bs) * mg.sp +
+                                 (long long)(mg.rp - mg.rb - MF_BORDER) * mg.sp + (mg.pinpos >= 0 ? 2ll * bs * (mg.sp + mg.rb + MF_BORDER) : 0);
 #define HOMMX_MF_K(BS_)                                                                                                                   \
   do {                                                                                                                                    \
     hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)std::min(bblocks, max_blocks)), dim3(256), 0, st, gd, P->Kst, P->Brhs, P->arena, \
                        nc, G.nn, G.ncode, G.t, jblocks, bblocks);                                                                         \
-    if (lines > 0)                                                                                                                        \
-      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min((nb * (long long)lines * mg.L + 255) / 256, max_blocks)), dim3(256), 0,  \
-                         st, gd, P->arena, nc, mg.pinpos);                                                                                \
+    if (pad_work > 0)                                                                                                                     \
+      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min((nb * pad_work + 255) / 256, max_blocks)), dim3(256), 0, st, gd,           \
+                         P->arena, nc, mg.pinpos);                                                                                        \
   } while (0)
       if (bs == 1) HOMMX_MF_K(1);
       else if (bs == 2) HOMMX_MF_K(2);
