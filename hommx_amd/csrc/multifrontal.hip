@@ -460,8 +460,9 @@ struct MfGroupDev {
 };
 
 // The eliminated COLUMNS of every (cell, front) of the group -- F11 (complete) and F21 with its border rows: original stencil entries +
-// the children's update matrices (+ the canonical loads in the border rows).  One thread per (row node i or the border, column node
-// j < ns): a BS x BS block, or the MF_BORDER x BS border strip.  F22 is not built (see the header comment).
+// the children's update matrices (+ the canonical loads in the border rows).  One thread per (row node i or the border, column UNKNOWN
+// q = j BS + b of an eliminated node j): BS values (or the MF_BORDER border entries) of one column, so that the 64 lanes of a wave
+// write -- and read from the children -- contiguous row segments.  F22 is not built (see the header comment).
 template <int BS>
 __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
                                                   double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks,
@@ -470,85 +471,69 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
   const int iblocks = (g.nloc + 1 + 3) / 4;
   // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches walk the block index with a grid stride
   for (long long blk0 = blockIdx.x; blk0 < nblocks; blk0 += gridDim.x) {
-  long long blk = blk0;
-  const int jb = (int)(blk % jblocks);
-  blk /= jblocks;
-  const int ib = (int)(blk % iblocks);
-  const long long batch = blk / iblocks;
-  const int i = ib * 4 + (tid >> 6), j = jb * 64 + (tid & 63);
-  if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) continue;
-  const long long cell = batch / g.nf;
-  const int f = (int)(batch % g.nf);
-  const int32_t* nodes = g.nodes + (long long)f * g.nloc;
-  double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
-  const int rj = j * BS;
-  if (i == g.nloc) {  // border rows: load case m against the unknowns of column node j
-    double v[MF_BORDER][BS];
+    long long blk = blk0;
+    const int jb = (int)(blk % jblocks);
+    blk /= jblocks;
+    const int ib = (int)(blk % iblocks);
+    const long long batch = blk / iblocks;
+    const int i = ib * 4 + (tid >> 6), q = jb * 64 + (tid & 63);
+    const int j = q / BS, b = q - j * BS;
+    if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) continue;
+    const long long cell = batch / g.nf;
+    const int f = (int)(batch % g.nf);
+    const int32_t* nodes = g.nodes + (long long)f * g.nloc;
+    double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+    if (i == g.nloc) {  // border rows: load case m against unknown q
+      double v[MF_BORDER];
 #pragma unroll
-    for (int m = 0; m < MF_BORDER; ++m)
+      for (int m = 0; m < MF_BORDER; ++m) v[m] = m < t ? Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + b) * nn + nodes[j]] : 0.0;
 #pragma unroll
-      for (int b = 0; b < BS; ++b) v[m][b] = m < t ? Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + b) * nn + nodes[j]] : 0.0;
+      for (int slot = 0; slot < 2; ++slot) {
+        const MfChild ch = g.child[f * 2 + slot];
+        if (!ch.valid) continue;
+        const int cj = g.cpos[((long long)f * 2 + slot) * g.nloc + j];
+        if (cj < 0) continue;
+        const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
+#pragma unroll
+        for (int m = 0; m < MF_BORDER; ++m) v[m] += U[(long long)(ch.rb + m) * ch.L + cj * BS + b];
+      }
+#pragma unroll
+      for (int m = 0; m < MF_BORDER; ++m) F[(long long)(g.sp + g.rb + m) * g.L + q] = v[m];
+      continue;
+    }
+    double v[BS];  // v[a] = F[(i, a)][(j, b)]
+#pragma unroll
+    for (int a = 0; a < BS; ++a) v[a] = 0.0;
+    const int code = g.code[((long long)f * g.nloc + i) * g.ns + j];
+    if (code >= 0) {
+      const double* Kc = Kst + ((cell * ncode + code) * BS) * BS * (long long)nn + nodes[i];
+#pragma unroll
+      for (int a = 0; a < BS; ++a) v[a] = Kc[((long long)a * BS + b) * nn];
+    }
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
       const MfChild ch = g.child[f * 2 + slot];
       if (!ch.valid) continue;
-      const int cj = g.cpos[((long long)f * 2 + slot) * g.nloc + j];
-      if (cj < 0) continue;
+      const int32_t* cp = g.cpos + ((long long)f * 2 + slot) * g.nloc;
+      const int ci = cp[i], cj = cp[j];
+      if (ci < 0 || cj < 0) continue;
       const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
+      // only entries on and below the diagonal of the child's update matrix are valid (its GEMM updates lower TILES, and a BS x BS
+      // diagonal block may straddle a tile boundary): a diagonal block is read through its lower triangle
+      const bool diag = ci == cj;
 #pragma unroll
-      for (int m = 0; m < MF_BORDER; ++m)
-#pragma unroll
-        for (int b = 0; b < BS; ++b) v[m][b] += U[(long long)(ch.rb + m) * ch.L + cj * BS + b];
-    }
-#pragma unroll
-    for (int m = 0; m < MF_BORDER; ++m)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) F[(long long)(g.sp + g.rb + m) * g.L + rj + b] = v[m][b];
-    continue;
-  }
-  double v[BS][BS];
-#pragma unroll
-  for (int a = 0; a < BS; ++a)
-#pragma unroll
-    for (int b = 0; b < BS; ++b) v[a][b] = 0.0;
-  const int code = g.code[((long long)f * g.nloc + i) * g.ns + j];
-  if (code >= 0) {
-    const double* Kc = Kst + ((cell * ncode + code) * BS) * BS * (long long)nn + nodes[i];
-#pragma unroll
-    for (int a = 0; a < BS; ++a)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) v[a][b] = Kc[((long long)a * BS + b) * nn];
-  }
-#pragma unroll
-  for (int slot = 0; slot < 2; ++slot) {
-    const MfChild ch = g.child[f * 2 + slot];
-    if (!ch.valid) continue;
-    const int32_t* cp = g.cpos + ((long long)f * 2 + slot) * g.nloc;
-    const int ci = cp[i], cj = cp[j];
-    if (ci < 0 || cj < 0) continue;
-    const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
-    // only entries on and below the diagonal of the child's update matrix are valid (its GEMM updates lower TILES, and a BS x BS
-    // diagonal block may straddle a tile boundary): a diagonal block is read through its lower triangle
-    const bool diag = ci == cj;
-#pragma unroll
-    for (int a = 0; a < BS; ++a)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) {
+      for (int a = 0; a < BS; ++a) {
         const int ra = (diag && b > a) ? b : a, rb = (diag && b > a) ? a : b;
-        v[a][b] += U[(long long)(ci * BS + ra) * ch.L + cj * BS + rb];
+        v[a] += U[(long long)(ci * BS + ra) * ch.L + cj * BS + rb];
       }
-  }
-  const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS;
+    }
+    const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS;
 #pragma unroll
-  for (int a = 0; a < BS; ++a)
+    for (int a = 0; a < BS; ++a) F[(long long)(ri + a) * g.L + q] = v[a];
+    if (i < g.ns && i != j) {  // F11 is kept complete (the leaf inverses read whole diagonal blocks)
 #pragma unroll
-    for (int b = 0; b < BS; ++b) F[(long long)(ri + a) * g.L + rj + b] = v[a][b];
-  if (i < g.ns && i != j) {  // F11 is kept complete (the leaf inverses read whole diagonal blocks)
-#pragma unroll
-    for (int a = 0; a < BS; ++a)
-#pragma unroll
-      for (int b = 0; b < BS; ++b) F[(long long)(rj + b) * g.L + ri + a] = v[a][b];
-  }
+      for (int a = 0; a < BS; ++a) F[(long long)q * g.L + ri + a] = v[a];
+    }
   }
 }
 
@@ -654,7 +639,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       ++gi;
       const long long nb = nc * mg.nf;  // matrices in this batch
       MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
-      const int jblocks = (mg.ns + 63) / 64;
+      const int jblocks = (mg.ns * bs + 63) / 64;  // 64 column unknowns per wave
       const long long bblocks = nb * ((gd.nloc + 1 + 3) / 4) * jblocks;
       const long long max_blocks = 1ll << 22;  // x 256 threads = 2^30 work-items per launch (the AQL limit is 2^32 - 1); grid-stride beyond
       const long long pad_work = (long long)(mg.sp + mg.rb + MF_BORDER) * (mg.sp - mg.ns * bs) + (long long)(mg.sp - mg.ns * bs) * mg.sp +
