@@ -51,7 +51,7 @@ extern "C" {
  *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the one-launch kernels
  *   HOMMX_MF_MIN_B         smallest plane block b routed to the nested-dissection (multifrontal) elimination instead of the plane
- *                          elimination (default: 65 for 3D elasticity, 289 for scalar 3D, 128 in 2D; 0: never)
+ *                          elimination (default: 65, i.e. every plane block the one-launch kernels do not take; 100 for scalar 3D; 0: never)
  *   HOMMX_MF_LEAF, HOMMX_MF_SPLIT_DEPTH, HOMMX_MF_G128_MIN_K, HOMMX_MF_NO_BORDER_SPLIT, HOMMX_MF_VERBOSE   tuning / A-B knobs of that route
  *   HOMMX_SMALL_WAVES      2 / 4: plane blocks b <= 48 take the LDS-resident multi-wave kernel (that many waves per macro cell)
  *                          instead of the one-wave-per-cell register kernel; for 48 < b <= 64 it sets that kernel's wave count
