@@ -80,6 +80,7 @@ struct MfPlan {
 };
 
 constexpr int MF_BORDER = 8;  // load rows per front (t <= 6)
+constexpr int MF_BUILD_ROWS = 16;  // rows of a front one workgroup of k_mf_build writes
 
 // stages of the elimination inside one front (mf_solve): about `stage` unknowns each, multiples of 32
 static inline int mf_stages(int sp, int stage) { return (stage <= 0 || sp < 2 * stage - 64) ? 1 : (sp + stage - 1) / stage; }
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
                                                   double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks,
                                                   long long nblocks) {
   const int tid = threadIdx.x;
-  const int iblocks = (g.nloc + 1 + 3) / 4;
+  const int iblocks = (g.nloc + 1 + MF_BUILD_ROWS - 1) / MF_BUILD_ROWS;
   // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches walk the block index with a grid stride
   for (long long blk0 = blockIdx.x; blk0 < nblocks; blk0 += gridDim.x) {
     long long blk = blk0;
@@ -479,13 +480,16 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
     blk /= jblocks;
     const int ib = (int)(blk % iblocks);
     const long long batch = blk / iblocks;
-    const int i = ib * 4 + (tid >> 6), q = jb * 64 + (tid & 63);
-    const int j = q / BS, b = q - j * BS;
-    if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) continue;
     const long long cell = batch / g.nf;
     const int f = (int)(batch % g.nf);
     const int32_t* nodes = g.nodes + (long long)f * g.nloc;
     double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+    const int q = jb * 64 + (tid & 63);
+    const int j = q / BS, b = q - j * BS;
+    // MF_BUILD_ROWS rows per workgroup, four at a time (small fronts: fewer, fatter workgroups -- the dispatch rate of tiny workgroups,
+    // not the traffic, bounded the build of 2D / scalar trees)
+    for (int i = ib * MF_BUILD_ROWS + (tid >> 6); i < (ib + 1) * MF_BUILD_ROWS; i += 4) {
+    if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) continue;
     if (i == g.nloc) {  // border rows: load case m against unknown q
       double v[MF_BORDER];
 #pragma unroll
@@ -537,6 +541,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
 #pragma unroll
       for (int a = 0; a < BS; ++a) F[(long long)q * g.L + ri + a] = v[a];
     }
+    }
   }
 }
 
@@ -545,28 +550,29 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
 // npad stride-L column walks):  rows [0, nrow) x the npad_s padding columns | the npad_s padding rows x [0, sp) | the npad_r rows behind
 // the border x [0, sp) | (root) 2 BS pin lines.
 template <int BS>
-__global__ void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int pinpos) {
+__global__ __launch_bounds__(256) void k_mf_pad(MfGroupDev g, double* __restrict__ arena, long long nc, int pinpos) {
   const int s0 = g.ns * BS, npad_s = g.sp - s0, nrow = g.sp + g.rb + MF_BORDER, npad_r = g.L - nrow, npin = pinpos >= 0 ? BS : 0;
-  const long long wA = (long long)nrow * npad_s, wB = (long long)npad_s * g.sp, wC = (long long)npad_r * g.sp, wD = 2ll * npin * nrow;
-  const long long per = wA + wB + wC + wD, total = nc * g.nf * per;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const long long batch = idx / per;
-    long long w = idx % per;
+  const int wA = nrow * npad_s, wB = npad_s * g.sp, wC = npad_r * g.sp, wD = 2 * npin * nrow, per = wA + wB + wC + wD;
+  const long long nb = nc * g.nf;
+  for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {  // one workgroup per front: 32-bit index arithmetic inside
     double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
-    if (w < wA) {  // column part of the identity padding: F[x][s0 + q], x < nrow
-      const int x = (int)(w / npad_s), p = s0 + (int)(w % npad_s);
-      F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
-    } else if ((w -= wA) < wB) {  // row part: F[s0 + q][x], x < sp
-      const int p = s0 + (int)(w / g.sp), x = (int)(w % g.sp);
-      F[(long long)p * g.L + x] = x == p ? 1.0 : 0.0;
-    } else if ((w -= wB) < wC) {  // F21 rows behind the border
-      const int p = nrow + (int)(w / g.sp), x = (int)(w % g.sp);
-      F[(long long)p * g.L + x] = 0.0;
-    } else {  // gauge: unit row and column of the pinned unknowns (the load rows lose their entry there too)
-      w -= wC;
-      const int q = (int)(w / (2 * nrow)), y = (int)(w % (2 * nrow)), p = pinpos * BS + q;
-      if (y < nrow) F[(long long)y * g.L + p] = y == p ? 1.0 : 0.0;
-      else if (y - nrow < g.sp) F[(long long)p * g.L + (y - nrow)] = (y - nrow) == p ? 1.0 : 0.0;
+    for (int w0 = threadIdx.x; w0 < per; w0 += 256) {
+      int w = w0;
+      if (w < wA) {  // column part of the identity padding: F[x][s0 + q], x < nrow
+        const int x = w / npad_s, p = s0 + w % npad_s;
+        F[(long long)x * g.L + p] = x == p ? 1.0 : 0.0;
+      } else if ((w -= wA) < wB) {  // row part: F[s0 + q][x], x < sp
+        const int p = s0 + w / g.sp, x = w % g.sp;
+        F[(long long)p * g.L + x] = x == p ? 1.0 : 0.0;
+      } else if ((w -= wB) < wC) {  // F21 rows behind the border
+        const int p = nrow + w / g.sp, x = w % g.sp;
+        F[(long long)p * g.L + x] = 0.0;
+      } else {  // gauge: unit row and column of the pinned unknowns (the load rows lose their entry there too)
+        w -= wC;
+        const int qq = w / (2 * nrow), y = w % (2 * nrow), p = pinpos * BS + qq;
+        if (y < nrow) F[(long long)y * g.L + p] = y == p ? 1.0 : 0.0;
+        else if (y - nrow < g.sp) F[(long long)p * g.L + (y - nrow)] = (y - nrow) == p ? 1.0 : 0.0;
+      }
     }
   }
 }
@@ -643,7 +649,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       const long long nb = nc * mg.nf;  // matrices in this batch
       MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
       const int jblocks = (mg.ns * bs + 63) / 64;  // 64 column unknowns per wave
-      const long long bblocks = nb * ((gd.nloc + 1 + 3) / 4) * jblocks;
+      const long long bblocks = nb * ((gd.nloc + 1 + MF_BUILD_ROWS - 1) / MF_BUILD_ROWS) * jblocks;
       const long long max_blocks = 1ll << 22;  // x 256 threads = 2^30 work-items per launch (the AQL limit is 2^32 - 1); grid-stride beyond
       const long long pad_work = (long long)(mg.sp + mg.rb + MF_BORDER) * (mg.sp - mg.ns * bs) + (long long)(mg.sp - mg.ns * bs) * mg.sp +
                                  (long long)(mg.rp - mg.rb - MF_BORDER) * mg.sp + (mg.pinpos >= 0 ? 2ll * bs * (mg.sp + mg.rb + MF_BORDER) : 0);
@@ -652,8 +658,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
     hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)std::min(bblocks, max_blocks)), dim3(256), 0, st, gd, P->Kst, P->Brhs, P->arena, \
                        nc, G.nn, G.ncode, G.t, jblocks, bblocks);                                                                         \
     if (pad_work > 0)                                                                                                                     \
-      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min((nb * pad_work + 255) / 256, max_blocks)), dim3(256), 0, st, gd,           \
-                         P->arena, nc, mg.pinpos);                                                                                        \
+      hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min(nb, max_blocks)), dim3(256), 0, st, gd, P->arena, nc, mg.pinpos);          \
   } while (0)
       if (bs == 1) HOMMX_MF_K(1);
       else if (bs == 2) HOMMX_MF_K(2);
