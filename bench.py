@@ -611,6 +611,7 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
     cells = np.arange(b, e)
     _, mask_h, values_h, M_h = workloads.c5_two_phase(shape, n, cells=cells)  # this rank's shard only
     plan = MicroCellPlan(3, n, "elasticity", device=local_rank)
+    plan.reserve(e - b)  # the workspace (fronts of a chunk of cells) is part of the plan, not of a timed step
     mask = torch.from_numpy(mask_h.astype(np.uint8)).to(dev)
     values = torch.from_numpy(values_h).to(dev)
     M = torch.from_numpy(M_h).to(dev)

@@ -17,6 +17,7 @@ EXPORTED_SYMBOLS = (
     "hommx_device_count",
     "hommx_plan_create",
     "hommx_plan_destroy",
+    "hommx_plan_reserve",
     "hommx_plan_dim",
     "hommx_plan_device",
     "hommx_plan_n_micro",
@@ -116,6 +117,8 @@ def load():
     lib.hommx_device_count.argtypes = []
     lib.hommx_plan_create.restype = C.c_int
     lib.hommx_plan_create.argtypes = [C.POINTER(vp), C.POINTER(PlanDesc)]
+    lib.hommx_plan_reserve.restype = C.c_int
+    lib.hommx_plan_reserve.argtypes = [vp, i64]
     lib.hommx_plan_destroy.restype = C.c_int
     lib.hommx_plan_destroy.argtypes = [vp]
     lib.hommx_plan_num_elements.restype = i64

@@ -42,6 +42,10 @@ class MicroCellPlan:
         self.kernel = self._lib.hommx_plan_kernel_name(h).decode()
         self.flops_per_solve = float(self._lib.hommx_plan_flops_per_solve(h))  # dense flops of the route, by its own model
 
+    def reserve(self, n_cells: int):
+        """Allocate the device workspace for batches of up to ``n_cells`` now (otherwise the first solve does it)."""
+        _lib.check(self._lib.hommx_plan_reserve(self._h, int(n_cells)), "hommx_plan_reserve")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.hommx_plan_destroy(self._h)

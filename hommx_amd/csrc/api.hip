@@ -171,6 +171,16 @@ int32_t hommx_plan_kind(const hommx_plan* p) { return p ? p->desc.kind : -1; }
 int64_t hommx_plan_num_elements(const hommx_plan* p) { return p ? p->n_el : 0; }
 int32_t hommx_plan_coef_components(const hommx_plan* p) { return p ? p->n_comp : 0; }
 int32_t hommx_plan_tensor_size(const hommx_plan* p) { return p ? p->t : 0; }
+int hommx_plan_reserve(hommx_plan* p, int64_t n_cells) {
+  if (!p) return fail(HOMMX_EINVAL, "null plan");
+  if (n_cells < 0) return fail(HOMMX_EINVAL, "negative n_cells");
+  if (p->family == FAM_FUSED2D || n_cells == 0) return HOMMX_OK;  // the fused 2D family keeps no scratch
+  HIP_TRY(hipSetDevice(p->desc.device));
+  int rc = hommx::blocked_reserve(p->ws, n_cells);
+  if (rc != 0) return fail(rc, "blocked path: %s", hommx::blocked_last_error());
+  return HOMMX_OK;
+}
+
 double hommx_plan_flops_per_solve(const hommx_plan* p) {
   if (!p) return 0.0;
   if (p->family == FAM_FUSED2D) {

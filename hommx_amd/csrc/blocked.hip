@@ -1428,6 +1428,12 @@ void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm,
   }
 }
 
+int blocked_reserve(BlockedWorkspace* ws, long long n_cells) {
+  if (!ws || n_cells <= 0) return 0;
+  if (ws->mf) return mf_reserve(ws, n_cells);
+  return ws_reserve(ws, n_cells, false);
+}
+
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out,
                   int32_t* d_info, hipStream_t st, double* d_corr) {
   if (ws->mf && !d_corr) return mf_solve(ws, ncells, d_coef, d_M, d_out, d_info, st);  // nested dissection (multifrontal.hip)

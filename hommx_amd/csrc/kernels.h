@@ -59,6 +59,8 @@ void blocked_workspace_destroy(BlockedWorkspace* ws);
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M,
                   double* d_out, int32_t* d_info, hipStream_t stream, double* d_corr = nullptr);
 const char* blocked_last_error();
+// allocate the workspace of the route for batches of up to n_cells (what the first solve would otherwise do)
+int blocked_reserve(BlockedWorkspace* ws, long long n_cells);
 // "small_wave" (b <= 48), "small_fused" (48 < b <= 64) or "blocked": the route blocked_solve takes for effective tensors
 const char* blocked_route_name(const BlockedWorkspace* ws);
 // dense flops one micro-cell solve executes on this route, by the route's own model (multifrontal: sum over the fronts of

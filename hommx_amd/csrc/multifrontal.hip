@@ -593,7 +593,7 @@ __global__ void k_mf_finalize(const double* __restrict__ C0, const double* __res
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------
-static int mf_reserve(BlockedWorkspace* ws, long long ncells) {
+int mf_reserve(BlockedWorkspace* ws, long long ncells) {
   MfPlan* P = ws->mf;
   const Geo& G = ws->G;
   double budget_gb = 128.0;  // fronts are big (C4 / C5: 0.2 GB per cell) and the card has 288 GB

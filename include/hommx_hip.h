@@ -77,6 +77,11 @@ int hommx_device_count(void);
 int hommx_plan_create(hommx_plan** out, const hommx_plan_desc* desc);
 int hommx_plan_destroy(hommx_plan* plan);
 
+/* Optional: allocate the plan's device workspace for batches of up to n_cells now instead of in the first solve (the nested-dissection
+ * route of the C4 / C5 problem size holds ~0.2 GB of fronts per cell of a chunk, up to min(128 GB, 0.6 x free HBM): about 2 s of
+ * hipMalloc that a benchmark wants outside its timed region).  The fused 2D family keeps no workspace: a no-op there. */
+int hommx_plan_reserve(hommx_plan* plan, int64_t n_cells);
+
 /* Shape queries: elements per micro mesh (2 n^2 / 6 n^3), coefficient doubles per element,
  * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), the descriptor fields, and the name of the
  * kernel route the plan's effective-tensor solves take: "fused2d" (2D scalar Poisson, n <= 32), "small_wave" (plane block

@@ -92,3 +92,17 @@ def test_blocked_workspace_in_several_chunks(tmp_path):
     assert not outs[0]["info"].any()
     assert np.allclose(outs[0]["A"], outs[1]["A"], rtol=1e-12, atol=0)
     assert np.allclose(outs[0]["chi"], outs[1]["chi"], rtol=1e-9, atol=1e-13)
+
+
+def test_plan_reserve_then_solve(rng):
+    """hommx_plan_reserve allocates the route's workspace up front; solves afterwards give the same bits as without it."""
+    from hommx_amd import MicroCellPlan, _lib
+
+    for dim, n, kind in ((3, 6, "elasticity"), (3, 6, "poisson"), (2, 16, "poisson")):
+        a, b = MicroCellPlan(dim, n, kind), MicroCellPlan(dim, n, kind)
+        b.reserve(50)
+        shape = (17, a.n_el) + ((a.n_comp,) if a.n_comp > 1 else ())
+        coef = rng.uniform(0.5, 2.0, size=shape)
+        assert np.array_equal(a.solve(coef), b.solve(coef))
+    with pytest.raises(_lib.HommxLibraryError):
+        a.reserve(-1)
