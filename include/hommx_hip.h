@@ -43,7 +43,8 @@ extern "C" {
 #define HOMMX_FLAG_FORCE_BLOCKED 1     /* use the generic blocked kernel family even where the fused 2D kernel applies */
 
 /* Environment knobs (development / tuning; read once, when a plan is created):
- *   HOMMX_BLOCKED_MEM_GB   workspace budget of the blocked family in GB (default min(64, half of the free HBM))
+ *   HOMMX_BLOCKED_MEM_GB   workspace budget of the blocked family in GB (default: plane elimination min(64, half of the free HBM),
+ *                          nested dissection min(128, 0.6 x free HBM) -- its fronts are 0.2 GB per C4 / C5 cell)
  *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256)
  *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products
  *   HOMMX_LEAF32           any value: 32x32 leaves only in the recursive block inverse
