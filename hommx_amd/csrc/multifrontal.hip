@@ -471,6 +471,7 @@ template <int BS>
 __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
                                                   double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks,
                                                   long long nblocks) {
+  constexpr int RPT = MF_BUILD_ROWS / 4;  // rows per thread
   const int tid = threadIdx.x;
   const int iblocks = (g.nloc + 1 + MF_BUILD_ROWS - 1) / MF_BUILD_ROWS;
   // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches walk the block index with a grid stride
@@ -486,61 +487,84 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
     double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
     const int q = jb * 64 + (tid & 63);
     const int j = q / BS, b = q - j * BS;
-    // MF_BUILD_ROWS rows per workgroup, four at a time (small fronts: fewer, fatter workgroups -- the dispatch rate of tiny workgroups,
-    // not the traffic, bounded the build of 2D / scalar trees)
-    for (int i = ib * MF_BUILD_ROWS + (tid >> 6); i < (ib + 1) * MF_BUILD_ROWS; i += 4) {
-    if (i > g.nloc || j >= g.ns || (i < g.ns && j > i)) continue;
-    if (i == g.nloc) {  // border rows: load case m against unknown q
-      double v[MF_BORDER];
+    if (j >= g.ns) continue;
+    // the two child slots of the front and where column node j sits in their boundary lists
+    const MfChild ch0 = g.child[f * 2], ch1 = g.child[f * 2 + 1];
+    const int32_t* cp0 = g.cpos + ((long long)f * 2) * g.nloc;
+    const int32_t* cp1 = cp0 + g.nloc;
+    const int cj0 = ch0.valid ? cp0[j] : -1, cj1 = ch1.valid ? cp1[j] : -1;
+    const double* U0 = arena + nc * ch0.offF + ((cell * ch0.nf + ch0.fidx) * (long long)ch0.L + ch0.sp) * ch0.L + ch0.sp;
+    const double* U1 = arena + nc * ch1.offF + ((cell * ch1.nf + ch1.fidx) * (long long)ch1.L + ch1.sp) * ch1.L + ch1.sp;
+    // RPT rows per thread (i0, i0 + 4, ...), in three passes -- indices, values, stores -- so that the dependent loads of all rows are in
+    // flight together (one row at a time the kernel is bound by load latency, not by traffic)
+    const int i0 = ib * MF_BUILD_ROWS + (tid >> 6);
+    int cd[RPT], c0[RPT], c1[RPT], nd[RPT];
+    bool ok[RPT];
 #pragma unroll
-      for (int m = 0; m < MF_BORDER; ++m) v[m] = m < t ? Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + b) * nn + nodes[j]] : 0.0;
+    for (int r = 0; r < RPT; ++r) {
+      const int i = i0 + 4 * r;
+      ok[r] = i < g.nloc && !(i < g.ns && j > i);
+      cd[r] = ok[r] ? (int)g.code[((long long)f * g.nloc + i) * g.ns + j] : -1;
+      c0[r] = (ok[r] && cj0 >= 0) ? cp0[i] : -1;
+      c1[r] = (ok[r] && cj1 >= 0) ? cp1[i] : -1;
+      nd[r] = ok[r] ? nodes[i] : 0;
+    }
+    double v[RPT][BS];  // v[r][a] = F[(i_r, a)][(j, b)]
 #pragma unroll
-      for (int slot = 0; slot < 2; ++slot) {
-        const MfChild ch = g.child[f * 2 + slot];
-        if (!ch.valid) continue;
-        const int cj = g.cpos[((long long)f * 2 + slot) * g.nloc + j];
-        if (cj < 0) continue;
-        const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
+    for (int r = 0; r < RPT; ++r) {
 #pragma unroll
-        for (int m = 0; m < MF_BORDER; ++m) v[m] += U[(long long)(ch.rb + m) * ch.L + cj * BS + b];
+      for (int a = 0; a < BS; ++a) v[r][a] = 0.0;
+      if (cd[r] >= 0) {
+        const double* Kc = Kst + ((cell * ncode + cd[r]) * BS) * BS * (long long)nn + nd[r];
+#pragma unroll
+        for (int a = 0; a < BS; ++a) v[r][a] = Kc[((long long)a * BS + b) * nn];
+      }
+      // only entries on and below the diagonal of a child's update matrix are valid (its GEMM updates lower TILES, and a BS x BS diagonal
+      // block may straddle a tile boundary): a diagonal block is read through its lower triangle
+      if (c0[r] >= 0) {
+        const bool diag = c0[r] == cj0;
+#pragma unroll
+        for (int a = 0; a < BS; ++a) {
+          const int ra = (diag && b > a) ? b : a, rb = (diag && b > a) ? a : b;
+          v[r][a] += U0[(long long)(c0[r] * BS + ra) * ch0.L + cj0 * BS + rb];
+        }
+      }
+      if (c1[r] >= 0) {
+        const bool diag = c1[r] == cj1;
+#pragma unroll
+        for (int a = 0; a < BS; ++a) {
+          const int ra = (diag && b > a) ? b : a, rb = (diag && b > a) ? a : b;
+          v[r][a] += U1[(long long)(c1[r] * BS + ra) * ch1.L + cj1 * BS + rb];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      if (!ok[r]) continue;
+      const int i = i0 + 4 * r;
+      const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS;
+#pragma unroll
+      for (int a = 0; a < BS; ++a) F[(long long)(ri + a) * g.L + q] = v[r][a];
+      if (i < g.ns && i != j) {  // F11 is kept complete (the leaf inverses read whole diagonal blocks)
+#pragma unroll
+        for (int a = 0; a < BS; ++a) F[(long long)q * g.L + ri + a] = v[r][a];
+      }
+    }
+    // border rows (load case m against unknown q): the thread row that reaches i == nloc
+    if (i0 <= g.nloc && g.nloc < i0 + 4 * RPT && ((g.nloc - i0) & 3) == 0) {
+      double w[MF_BORDER];
+#pragma unroll
+      for (int m = 0; m < MF_BORDER; ++m) w[m] = m < t ? Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + b) * nn + nodes[j]] : 0.0;
+      if (cj0 >= 0) {
+#pragma unroll
+        for (int m = 0; m < MF_BORDER; ++m) w[m] += U0[(long long)(ch0.rb + m) * ch0.L + cj0 * BS + b];
+      }
+      if (cj1 >= 0) {
+#pragma unroll
+        for (int m = 0; m < MF_BORDER; ++m) w[m] += U1[(long long)(ch1.rb + m) * ch1.L + cj1 * BS + b];
       }
 #pragma unroll
-      for (int m = 0; m < MF_BORDER; ++m) F[(long long)(g.sp + g.rb + m) * g.L + q] = v[m];
-      continue;
-    }
-    double v[BS];  // v[a] = F[(i, a)][(j, b)]
-#pragma unroll
-    for (int a = 0; a < BS; ++a) v[a] = 0.0;
-    const int code = g.code[((long long)f * g.nloc + i) * g.ns + j];
-    if (code >= 0) {
-      const double* Kc = Kst + ((cell * ncode + code) * BS) * BS * (long long)nn + nodes[i];
-#pragma unroll
-      for (int a = 0; a < BS; ++a) v[a] = Kc[((long long)a * BS + b) * nn];
-    }
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const MfChild ch = g.child[f * 2 + slot];
-      if (!ch.valid) continue;
-      const int32_t* cp = g.cpos + ((long long)f * 2 + slot) * g.nloc;
-      const int ci = cp[i], cj = cp[j];
-      if (ci < 0 || cj < 0) continue;
-      const double* U = arena + nc * ch.offF + ((cell * ch.nf + ch.fidx) * (long long)ch.L + ch.sp) * ch.L + ch.sp;
-      // only entries on and below the diagonal of the child's update matrix are valid (its GEMM updates lower TILES, and a BS x BS
-      // diagonal block may straddle a tile boundary): a diagonal block is read through its lower triangle
-      const bool diag = ci == cj;
-#pragma unroll
-      for (int a = 0; a < BS; ++a) {
-        const int ra = (diag && b > a) ? b : a, rb = (diag && b > a) ? a : b;
-        v[a] += U[(long long)(ci * BS + ra) * ch.L + cj * BS + rb];
-      }
-    }
-    const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS;
-#pragma unroll
-    for (int a = 0; a < BS; ++a) F[(long long)(ri + a) * g.L + q] = v[a];
-    if (i < g.ns && i != j) {  // F11 is kept complete (the leaf inverses read whole diagonal blocks)
-#pragma unroll
-      for (int a = 0; a < BS; ++a) F[(long long)q * g.L + ri + a] = v[a];
-    }
+      for (int m = 0; m < MF_BORDER; ++m) F[(long long)(g.sp + g.rb + m) * g.L + q] = w[m];
     }
   }
 }
