@@ -956,7 +956,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
   if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
   ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;
-  if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && G.b > 64) {
+  if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && (G.b > 64 || !ws->small_fused)) {
     if (int rc = mf_plan_create(&ws->mf, G)) {
       delete ws;
       return rc;
@@ -968,8 +968,9 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
 
 const char* blocked_route_name(const BlockedWorkspace* ws) {
   if (!ws) return "blocked";
+  if (ws->mf) return "multifrontal";
   if (ws->G.b <= 64 && ws->small_fused) return (ws->G.b <= 48 && ws->small_waves != 2 && ws->small_waves != 4) ? "small_wave" : "small_fused";
-  return ws->mf ? "multifrontal" : "blocked";
+  return "blocked";
 }
 
 double blocked_flops_per_cell(const BlockedWorkspace* ws) {

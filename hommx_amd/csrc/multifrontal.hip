@@ -470,10 +470,12 @@ struct MfGroupDev {
 template <int BS>
 __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
                                                   double* __restrict__ arena, long long nc, int nn, int ncode, int t, int jblocks,
-                                                  long long nblocks) {
+                                                  int pshift, long long nblocks) {
   constexpr int RPT = MF_BUILD_ROWS / 4;  // rows per thread
   const int tid = threadIdx.x;
-  const int iblocks = (g.nloc + 1 + MF_BUILD_ROWS - 1) / MF_BUILD_ROWS;
+  // narrow fronts (ns * BS <= 32 column unknowns) pack 2^pshift rows into one wave: lane = (row within the pack, column unknown)
+  const int rows_blk = MF_BUILD_ROWS << pshift;
+  const int iblocks = (g.nloc + 1 + rows_blk - 1) / rows_blk;
   // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches walk the block index with a grid stride
   for (long long blk0 = blockIdx.x; blk0 < nblocks; blk0 += gridDim.x) {
     long long blk = blk0;
@@ -485,7 +487,8 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
     const int f = (int)(batch % g.nf);
     const int32_t* nodes = g.nodes + (long long)f * g.nloc;
     double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
-    const int q = jb * 64 + (tid & 63);
+    const int lpr = 64 >> pshift;  // lanes per row
+    const int q = jb * 64 + (tid & (lpr - 1));
     const int j = q / BS, b = q - j * BS;
     if (j >= g.ns) continue;
     // the two child slots of the front and where column node j sits in their boundary lists
@@ -497,12 +500,13 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
     const double* U1 = arena + nc * ch1.offF + ((cell * ch1.nf + ch1.fidx) * (long long)ch1.L + ch1.sp) * ch1.L + ch1.sp;
     // RPT rows per thread (i0, i0 + 4, ...), in three passes -- indices, values, stores -- so that the dependent loads of all rows are in
     // flight together (one row at a time the kernel is bound by load latency, not by traffic)
-    const int i0 = ib * MF_BUILD_ROWS + (tid >> 6);
+    const int i0 = ib * rows_blk + ((tid >> 6) << pshift) + ((tid & 63) >> (6 - pshift));
+    const int istep = 4 << pshift;
     int cd[RPT], c0[RPT], c1[RPT], nd[RPT];
     bool ok[RPT];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      const int i = i0 + 4 * r;
+      const int i = i0 + istep * r;
       ok[r] = i < g.nloc && !(i < g.ns && j > i);
       cd[r] = ok[r] ? (int)g.code[((long long)f * g.nloc + i) * g.ns + j] : -1;
       c0[r] = (ok[r] && cj0 >= 0) ? cp0[i] : -1;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       if (!ok[r]) continue;
-      const int i = i0 + 4 * r;
+      const int i = i0 + istep * r;
       const int ri = i < g.ns ? i * BS : g.sp + (i - g.ns) * BS;
 #pragma unroll
       for (int a = 0; a < BS; ++a) F[(long long)(ri + a) * g.L + q] = v[r][a];
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void k_mf_build(MfGroupDev g, const double* __
       }
     }
     // border rows (load case m against unknown q): the thread row that reaches i == nloc
-    if (i0 <= g.nloc && g.nloc < i0 + 4 * RPT && ((g.nloc - i0) & 3) == 0) {
+    if (i0 <= g.nloc && g.nloc < i0 + istep * RPT && (g.nloc - i0) % istep == 0) {
       double w[MF_BORDER];
 #pragma unroll
       for (int m = 0; m < MF_BORDER; ++m) w[m] = m < t ? Brhs[cell * (long long)t * BS * nn + ((long long)m * BS + b) * nn + nodes[j]] : 0.0;
@@ -673,14 +677,17 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
       const long long nb = nc * mg.nf;  // matrices in this batch
       MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
       const int jblocks = (mg.ns * bs + 63) / 64;  // 64 column unknowns per wave
-      const long long bblocks = nb * ((gd.nloc + 1 + MF_BUILD_ROWS - 1) / MF_BUILD_ROWS) * jblocks;
+      int pshift = 0;  // rows of a narrow front packed into one wave (k_mf_build)
+      while (pshift < 3 && mg.ns * bs * (2 << pshift) <= 64) ++pshift;
+      const int rows_blk = MF_BUILD_ROWS << pshift;
+      const long long bblocks = nb * ((gd.nloc + 1 + rows_blk - 1) / rows_blk) * jblocks;
       const long long max_blocks = 1ll << 22;  // x 256 threads = 2^30 work-items per launch (the AQL limit is 2^32 - 1); grid-stride beyond
       const long long pad_work = (long long)(mg.sp + mg.rb + MF_BORDER) * (mg.sp - mg.ns * bs) + (long long)(mg.sp - mg.ns * bs) * mg.sp +
                                  (long long)(mg.rp - mg.rb - MF_BORDER) * mg.sp + (mg.pinpos >= 0 ? 2ll * bs * (mg.sp + mg.rb + MF_BORDER) : 0);
 #define HOMMX_MF_K(BS_)                                                                                                                   \
   do {                                                                                                                                    \
     hipLaunchKernelGGL((k_mf_build<BS_>), dim3((unsigned)std::min(bblocks, max_blocks)), dim3(256), 0, st, gd, P->Kst, P->Brhs, P->arena, \
-                       nc, G.nn, G.ncode, G.t, jblocks, bblocks);                                                                         \
+                       nc, G.nn, G.ncode, G.t, jblocks, pshift, bblocks);                                                                 \
     if (pad_work > 0)                                                                                                                     \
       hipLaunchKernelGGL((k_mf_pad<BS_>), dim3((unsigned)std::min(nb, max_blocks)), dim3(256), 0, st, gd, P->arena, nc, mg.pinpos);          \
   } while (0)
