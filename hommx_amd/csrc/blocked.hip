@@ -1431,7 +1431,7 @@ void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm,
 
 int blocked_reserve(BlockedWorkspace* ws, long long n_cells) {
   if (!ws || n_cells <= 0) return 0;
-  if (ws->mf) return mf_reserve(ws, n_cells);
+  if (ws->mf) return mf_reserve(ws, n_cells, true);
   return ws_reserve(ws, n_cells, false);
 }
 

@@ -87,7 +87,7 @@ extern thread_local std::string g_berr;
 int mf_plan_create(MfPlan** out, const Geo& G);
 void mf_plan_destroy(MfPlan* p);
 double mf_flops_per_cell(const MfPlan* p);
-int mf_reserve(BlockedWorkspace* ws, long long ncells);
+int mf_reserve(BlockedWorkspace* ws, long long ncells, bool ahead);
 int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
              hipStream_t st);
 // K1 of the blocked family (stencil rows, loads, C0 of `nc` cells into the given buffers), shared by both eliminations: each route owns

@@ -629,10 +629,16 @@ __global__ void k_mf_finalize(const double* __restrict__ C0, const double* __res
 // ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------
-int mf_reserve(BlockedWorkspace* ws, long long ncells) {
+int mf_reserve(BlockedWorkspace* ws, long long ncells, bool ahead) {
   MfPlan* P = ws->mf;
   const Geo& G = ws->G;
-  double budget_gb = 128.0;  // fronts are big (C4 / C5: 0.2 GB per cell) and the card has 288 GB
+  const long long stencil = (long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36;
+  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + stencil);
+  // Fronts are big (C4 / C5: 0.2 GB per cell) and the card has 288 GB, but a call pays for what it allocates (2.5 - 3 s per 64 GB
+  // measured) and the throughput is nearly flat from 256 cells per chunk (C4: 2,390 / 2,510 / 2,580 / 2,655 / 2,654 solves/s at 64 / 128 /
+  // 192 / 256 / 384 cells; all of C5: 2,590 with 64 GB, 2,640 with 128).  A solve that has to allocate takes 64 GB (more, to 128 GB, only
+  // where 256 cells need it); hommx_plan_reserve -- the caller pays ahead of many batches -- takes 128 GB.
+  double budget_gb = ahead ? 128.0 : std::max(64.0, std::min(128.0, 256.0 * 1e-9 * (double)per_cell));
   {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
@@ -641,8 +647,6 @@ int mf_reserve(BlockedWorkspace* ws, long long ncells) {
     }
   }
   if (ws->budget_gb_env > 0.0) budget_gb = ws->budget_gb_env;
-  const long long stencil = (long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36;
-  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + stencil);
   long long chunk = (long long)(budget_gb * 1e9) / per_cell;
   if (chunk < 1) chunk = 1;
   if (chunk > 4096) chunk = 4096;
@@ -761,7 +765,7 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
              hipStream_t st) {
   MfPlan* P = ws->mf;
   const Geo& G = ws->G;
-  if (int rc = mf_reserve(ws, ncells)) return rc;
+  if (int rc = mf_reserve(ws, ncells, false)) return rc;
   if (d_info) MTRY(hipMemsetAsync(d_info, 0, sizeof(int32_t) * ncells, st));
   long long step_cells = P->chunk;
   {

@@ -44,7 +44,7 @@ extern "C" {
 
 /* Environment knobs (development / tuning; read once, when a plan is created):
  *   HOMMX_BLOCKED_MEM_GB   workspace budget of the blocked family in GB (default: plane elimination min(64, half of the free HBM),
- *                          nested dissection min(128, 0.6 x free HBM) -- its fronts are 0.2 GB per C4 / C5 cell)
+ *                          nested dissection min(64 -- 128 through hommx_plan_reserve --, 0.6 x free HBM): its fronts are 0.2 GB per C4 / C5 cell)
  *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256)
  *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products
  *   HOMMX_LEAF32           any value: 32x32 leaves only in the recursive block inverse
@@ -80,9 +80,10 @@ int hommx_device_count(void);
 int hommx_plan_create(hommx_plan** out, const hommx_plan_desc* desc);
 int hommx_plan_destroy(hommx_plan* plan);
 
-/* Optional: allocate the plan's device workspace for batches of up to n_cells now instead of in the first solve (the nested-dissection
- * route of the C4 / C5 problem size holds ~0.2 GB of fronts per cell of a chunk, up to min(128 GB, 0.6 x free HBM): about 2 s of
- * hipMalloc that a benchmark wants outside its timed region).  The fused 2D family keeps no workspace: a no-op there. */
+/* Optional: allocate the plan's device workspace for batches of up to n_cells now instead of in the first solve.  The nested-dissection
+ * route of the C4 / C5 problem size holds ~0.2 GB of fronts per cell of a chunk: a first solve allocates up to min(64 GB, 0.6 x free HBM),
+ * this call up to 128 GB (2 % more throughput over many batches) -- 2 to 6 s of hipMalloc that a benchmark wants outside its timed
+ * region.  The fused 2D family keeps no workspace: a no-op there. */
 int hommx_plan_reserve(hommx_plan* plan, int64_t n_cells);
 
 /* Shape queries: elements per micro mesh (2 n^2 / 6 n^3), coefficient doubles per element,
