@@ -23,6 +23,7 @@
 //     index maps (GatherC epilogue of k_gemm_tile) and writes the front's update matrix once.  Only F11 / F21 (the eliminated columns)
 //     are written by k_mf_build: stencil entries + the children's entries, every entry exactly once -- no memset, no atomics.
 //   * Nodes are numbered in elimination order everywhere, so child -> parent maps are monotone and only lower triangles are ever needed.
+//   * The two halves of every chunk of cells run side by side on two streams (the caller's and a plan-owned one, mf_solve).
 // Gauge: the last node is pinned in the root front (cell_problem.py:349-361).
 #include <hip/hip_runtime.h>
 
