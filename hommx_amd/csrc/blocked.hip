@@ -956,6 +956,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
   if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
   ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;
+  if (const char* e = getenv("HOMMX_MF_CORR")) ws->mf_corr = atoi(e) != 0;
   if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && (G.b > 64 || !ws->small_fused)) {
     if (int rc = mf_plan_create(&ws->mf, G)) {
       delete ws;
@@ -1006,6 +1007,7 @@ static void ws_free(BlockedWorkspace* ws) {
 void blocked_workspace_destroy(BlockedWorkspace* ws) {
   if (!ws) return;
   if (ws->mf) mf_plan_destroy(ws->mf);
+  if (ws->mf_keep) mf_plan_destroy(ws->mf_keep);
   ws_free(ws);
   delete ws;
 }
@@ -1399,6 +1401,10 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp) {
                                                                          // (= A11^-1 + Xm^T T^-1 Xm): lower tiles, mirrored in place
 }
 
+void launch_center_corr(BlockedWorkspace* ws, double* corr, long long nc, hipStream_t st) {
+  hipLaunchKernelGGL(k_center_corr, dim3((unsigned)(nc * ws->G.t)), dim3(256), 0, st, ws->G, corr);
+}
+
 void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st, double* Kst, double* Brhs,
                      double* C0) {
   const Geo& G = ws->G;
@@ -1431,13 +1437,18 @@ void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm,
 
 int blocked_reserve(BlockedWorkspace* ws, long long n_cells) {
   if (!ws || n_cells <= 0) return 0;
-  if (ws->mf) return mf_reserve(ws, n_cells, true);
+  if (ws->mf) return mf_reserve(ws, ws->mf, n_cells, true);
   return ws_reserve(ws, n_cells, false);
 }
 
 int blocked_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out,
                   int32_t* d_info, hipStream_t st, double* d_corr) {
-  if (ws->mf && !d_corr) return mf_solve(ws, ncells, d_coef, d_M, d_out, d_info, st);  // nested dissection (multifrontal.hip)
+  if (ws->mf && !d_corr) return mf_solve(ws, ws->mf, ncells, d_coef, d_M, d_out, d_info, st);  // nested dissection (multifrontal.hip)
+  if (ws->mf && ws->mf_corr) {  // correctors on the same route: a second plan whose fronts keep their factors for the back substitution
+    if (!ws->mf_keep)
+      if (int rc = mf_plan_create(&ws->mf_keep, ws->G, true)) return rc;
+    return mf_solve(ws, ws->mf_keep, ncells, d_coef, d_M, d_out, d_info, st, d_corr);
+  }
   if (int rc = ws_reserve(ws, ncells, d_corr != nullptr)) return rc;
   const Geo& G = ws->G;
   const int n = G.n, Bp = G.Bp;

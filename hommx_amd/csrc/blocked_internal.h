@@ -32,6 +32,8 @@ struct BlockedWorkspace {
   double *hS = nullptr, *hW = nullptr, *hR = nullptr, *Xa = nullptr, *Xb = nullptr, *Y = nullptr;
   // nested-dissection route (3D, large plane blocks): symbolic analysis + arena, owned by multifrontal.hip
   MfPlan* mf = nullptr;
+  MfPlan* mf_keep = nullptr;   // corrector plan of the same route (fronts keep their factors), created by the first corrector call
+  bool mf_corr = true;         // HOMMX_MF_CORR=0: correctors of multifrontal plans take the plane elimination (A/B runs)
   int mf_min_b = 192;          // smallest plane block b routed to the multifrontal elimination (set per dim / unknowns per node when the
                                // workspace is created; HOMMX_MF_MIN_B overrides, 0: never)
   bool mf_no_border_split = false;  // HOMMX_MF_NO_BORDER_SPLIT (A/B runs)
@@ -84,12 +86,15 @@ void invert(const Ctx& c, double* S, int off, int size, double* tmp);
 extern thread_local std::string g_berr;
 
 // multifrontal.hip
-int mf_plan_create(MfPlan** out, const Geo& G);
+int mf_plan_create(MfPlan** out, const Geo& G, bool keep = false);
 void mf_plan_destroy(MfPlan* p);
 double mf_flops_per_cell(const MfPlan* p);
-int mf_reserve(BlockedWorkspace* ws, long long ncells, bool ahead);
-int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
-             hipStream_t st);
+int mf_reserve(BlockedWorkspace* ws, MfPlan* P, long long ncells, bool ahead);
+// effective tensors, and with the corrector plan (keep = true) and d_corr != nullptr the correctors [cell][t][n^d bs] as well
+int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
+             hipStream_t st, double* d_corr = nullptr);
+// remove the mean of every component of nc x t corrector fields (blocked.hip)
+void launch_center_corr(BlockedWorkspace* ws, double* corr, long long nc, hipStream_t st);
 // K1 of the blocked family (stencil rows, loads, C0 of `nc` cells into the given buffers), shared by both eliminations: each route owns
 // its buffers (a plan may serve effective tensors on one route and correctors on the other, with different chunk sizes)
 void launch_assembly(BlockedWorkspace* ws, const double* coef, const double* Mm, long long nc, hipStream_t st, double* Kst, double* Brhs,

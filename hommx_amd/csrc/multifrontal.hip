@@ -74,9 +74,11 @@ struct MfPlan {
   long long scratch_per_cell = 0;   // doubles: inverse scratch of the largest group
   double flops_per_cell = 0.0;      // executed dense flops by the model of mf_solve (staged elimination + Schur update) on the padded sizes
   int stage = 192;                  // HOMMX_MF_STAGE: unknowns per elimination stage inside a front (0: one stage)
+  bool keep = false;                // corrector plan: every front keeps its own place in the arena (the back substitution reads N and X of all of them)
+  long long vbuf_per_cell = 0;      // doubles: solution vectors of the largest group, [nf][MF_BORDER][L] (corrector plan)
   // chunk buffers
   long long chunk = 0;
-  double *arena = nullptr, *scratch = nullptr;
+  double *arena = nullptr, *scratch = nullptr, *vbuf = nullptr;
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;  // K1 output of this route's chunks (the plane elimination keeps its own)
   // second stream of mf_solve: a chunk runs as two halves side by side (HOMMX_MF_STREAMS = 1: off)
   int streams = 2;
@@ -211,7 +213,7 @@ void mf_plan_destroy(MfPlan* p) {
     if (g.d_dpos) (void)hipFree(g.d_dpos);
     if (g.d_child) (void)hipFree(g.d_child);
   }
-  for (double* q : {p->arena, p->scratch, p->Kst, p->Brhs, p->C0})
+  for (double* q : {p->arena, p->scratch, p->vbuf, p->Kst, p->Brhs, p->C0})
     if (q) (void)hipFree(q);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
@@ -219,10 +221,11 @@ void mf_plan_destroy(MfPlan* p) {
   delete p;
 }
 
-int mf_plan_create(MfPlan** out, const Geo& G) {
+int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
   *out = nullptr;
   MfPlan* P = new MfPlan();
   P->G = G;
+  P->keep = keep;
   const int dim = G.dim, n = G.n, bs = G.bs, nn = G.nn;
   TreeBuilder tb;
   tb.dim = dim;
@@ -347,6 +350,8 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
   }
   for (int k = 0; k < nsn; ++k)
     for (int c : sn[k].children) expiry[pos_of[sn[c].group]] = std::max(expiry[pos_of[sn[c].group]], pos_of[sn[k].group]);
+  if (keep)
+    for (int t = 0; t < ng; ++t) expiry[t] = ng;  // nothing is ever released
   {
     struct Live {
       long long off, size;
@@ -370,6 +375,7 @@ int mf_plan_create(MfPlan** out, const Geo& G) {
       MfGroup& mg = P->groups[t];
       mg.offF = place((long long)mg.nf * mg.L * mg.L, expiry[t], t);
       P->scratch_per_cell = std::max(P->scratch_per_cell, (long long)mg.nf * mg.sp * mg.sp);
+      if (keep) P->vbuf_per_cell = std::max(P->vbuf_per_cell, (long long)mg.nf * MF_BORDER * mg.L);
       {  // inverse of a stage si^3, X_i 2 si^2 below, column update 2 below rem si, Schur update s r^2 (lower tiles)
         const int nst = mf_stages(mg.sp, P->stage);
         double f = (double)mg.sp * mg.rp * mg.rp;
@@ -628,13 +634,60 @@ __global__ void k_mf_finalize(const double* __restrict__ C0, const double* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// correctors: back substitution down the tree (corrector plan: every front still holds N_i and X_i of its stages)
+//   per front and load case m, with v = the solution at the front's unknowns in front order:
+//     v[boundary]  = the solution found by the ancestors (gathered from the output array)
+//     v[stage i]   = X_i[:, border m] - X_i[:, later stages and boundary] v[later stages and boundary]     (last stage first)
+//   X_i = N_i E_i^T, and border column m of X_i is N_i times the forward-eliminated load vector (the border rows took part in the
+//   elimination).  The products run as thin batched GEMMs (k_gemm_tile, M = 8 load rows); V is [front][8][L].
+// ---------------------------------------------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(256) void k_mf_bs_init(MfGroupDev g, const double* __restrict__ arena, double* __restrict__ V,
+                                                    const double* __restrict__ corr, long long nc, int t, long long ndof) {
+  const long long nb = nc * g.nf;
+  for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+    const long long cell = batch / g.nf;
+    const int f = (int)(batch % g.nf);
+    const int32_t* nodes = g.nodes + (long long)f * g.nloc;
+    const double* F = arena + nc * g.offF + batch * (long long)g.L * g.L;
+    double* v = V + batch * (long long)MF_BORDER * g.L;
+    for (int w = threadIdx.x; w < MF_BORDER * g.L; w += 256) {
+      const int m = w / g.L, q = w % g.L;
+      double x = 0.0;
+      if (q < g.sp) x = F[(long long)q * g.L + g.sp + g.rb + m];
+      else if (q < g.sp + g.rb && m < t) {
+        const int p = q - g.sp;
+        x = corr[(cell * t + m) * ndof + (long long)nodes[g.ns + p / BS] * BS + p % BS];
+      }
+      v[w] = x;
+    }
+  }
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) void k_mf_bs_store(MfGroupDev g, const double* __restrict__ V, double* __restrict__ corr, long long nc,
+                                                     int t, long long ndof) {
+  const long long nb = nc * g.nf;
+  const int s0 = g.ns * BS;
+  for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+    const long long cell = batch / g.nf;
+    const int f = (int)(batch % g.nf);
+    const int32_t* nodes = g.nodes + (long long)f * g.nloc;
+    const double* v = V + batch * (long long)MF_BORDER * g.L;
+    for (int w = threadIdx.x; w < t * s0; w += 256) {
+      const int m = w / s0, q = w % s0;
+      corr[(cell * t + m) * ndof + (long long)nodes[q / BS] * BS + q % BS] = v[m * g.L + q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------------------------
-int mf_reserve(BlockedWorkspace* ws, long long ncells, bool ahead) {
-  MfPlan* P = ws->mf;
+int mf_reserve(BlockedWorkspace* ws, MfPlan* P, long long ncells, bool ahead) {
   const Geo& G = ws->G;
   const long long stencil = (long long)G.ncode * G.bs * G.bs * G.nn + (long long)G.t * G.bs * G.nn + 36;
-  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + stencil);
+  const long long per_cell = 8ll * (P->arena_per_cell + P->scratch_per_cell + P->vbuf_per_cell + stencil);
   // Fronts are big (C4 / C5: 0.2 GB per cell) and the card has 288 GB, but a call pays for what it allocates (2.5 - 3 s per 64 GB
   // measured) and the throughput is nearly flat from 256 cells per chunk (C4: 2,390 / 2,510 / 2,580 / 2,655 / 2,654 solves/s at 64 / 128 /
   // 192 / 256 / 384 cells; all of C5: 2,590 with 64 GB, 2,640 with 128).  A solve that has to allocate takes 64 GB (more, to 128 GB, only
@@ -653,13 +706,14 @@ int mf_reserve(BlockedWorkspace* ws, long long ncells, bool ahead) {
   if (chunk > 4096) chunk = 4096;
   if (chunk > ncells) chunk = ncells;
   if (chunk <= P->chunk) return 0;
-  for (double** p : {&P->arena, &P->scratch, &P->Kst, &P->Brhs, &P->C0}) {
+  for (double** p : {&P->arena, &P->scratch, &P->vbuf, &P->Kst, &P->Brhs, &P->C0}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   P->chunk = 0;
   MTRY(hipMalloc(&P->arena, 8ll * chunk * P->arena_per_cell));
   MTRY(hipMalloc(&P->scratch, 8ll * chunk * P->scratch_per_cell));
+  if (P->vbuf_per_cell) MTRY(hipMalloc(&P->vbuf, 8ll * chunk * P->vbuf_per_cell));
   MTRY(hipMalloc(&P->Kst, 8ll * chunk * G.ncode * G.bs * G.bs * G.nn));
   MTRY(hipMalloc(&P->Brhs, 8ll * chunk * G.t * G.bs * G.nn));
   MTRY(hipMalloc(&P->C0, 8ll * chunk * 36));
@@ -678,8 +732,7 @@ struct MfHalf {
 };
 
 // all launches of one group of fronts for one half
-void mf_group_step(BlockedWorkspace* ws, const MfHalf& h, const MfGroup& mg, int gi, int32_t* d_info) {
-  MfPlan* P = ws->mf;
+void mf_group_step(BlockedWorkspace* ws, MfPlan* P, const MfHalf& h, const MfGroup& mg, int gi, int32_t* d_info) {
   const Geo& G = ws->G;
   const int bs = G.bs;
   const long long nc = h.nc;
@@ -760,13 +813,51 @@ void mf_group_step(BlockedWorkspace* ws, const MfHalf& h, const MfGroup& mg, int
   }
 }
 
+// back substitution of one group of fronts for one half (corrector plan): the unknowns the group eliminates, for every load case
+void mf_backsub_step(BlockedWorkspace* ws, MfPlan* P, const MfHalf& h, const MfGroup& mg, double* d_corr) {
+  const Geo& G = ws->G;
+  const int bs = G.bs;
+  const long long nc = h.nc, nb = nc * mg.nf, ndof = (long long)G.nn * bs;
+  hipStream_t st = h.st;
+  double* arena = P->arena + h.base * P->arena_per_cell;
+  double* V = P->vbuf + h.base * P->vbuf_per_cell;
+  double* corr = d_corr + h.c0 * G.t * ndof;
+  MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
+  const unsigned blocks = (unsigned)std::min(nb, 1ll << 22);
+#define HOMMX_MF_BS(KERN, ...)                                                                           \
+  do {                                                                                                   \
+    if (bs == 1) hipLaunchKernelGGL((KERN<1>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__);             \
+    else if (bs == 2) hipLaunchKernelGGL((KERN<2>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL((KERN<3>), dim3(blocks), dim3(256), 0, st, __VA_ARGS__);                     \
+  } while (0)
+  HOMMX_MF_BS(k_mf_bs_init, gd, arena, V, corr, nc, G.t, ndof);
+  const double* F = arena + nc * mg.offF;
+  const long long sF = (long long)mg.L * mg.L, sV = (long long)MF_BORDER * mg.L;
+  Ctx c{ws, nb, st, nullptr, 0};
+  const int nst = mf_stages(mg.sp, P->stage);
+  int off = mg.sp;
+  for (int i = nst - 1; i >= 0; --i) {  // v[stage i] -= X_i[:, later stages and boundary] v[...]: C (8 x si) -= A (8 x rest) B^T (B = X_i: si x rest)
+    const int si = mf_stage_size(mg.sp, nst, i);
+    off -= si;
+    const int rest = mg.sp + mg.rb - (off + si);
+    if (rest > 0)
+      gemm(c, false, true, MF_BORDER, si, rest, -1.0, V + off + si, mg.L, sV, F + (long long)off * mg.L + off + si, mg.L, sF, 1.0, V + off,
+           mg.L, sV);
+  }
+  HOMMX_MF_BS(k_mf_bs_store, gd, V, corr, nc, G.t, ndof);
+#undef HOMMX_MF_BS
+}
+
 }  // namespace
 
-int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
-             hipStream_t st) {
-  MfPlan* P = ws->mf;
+int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,
+             hipStream_t st, double* d_corr) {
   const Geo& G = ws->G;
-  if (int rc = mf_reserve(ws, ncells, false)) return rc;
+  if (d_corr && !P->keep) {
+    g_berr = "mf_solve: correctors need the corrector plan";
+    return HOMMX_EINVAL;
+  }
+  if (int rc = mf_reserve(ws, P, ncells, false)) return rc;
   if (d_info) MTRY(hipMemsetAsync(d_info, 0, sizeof(int32_t) * ncells, st));
   long long step_cells = P->chunk;
   {
@@ -805,13 +896,19 @@ int mf_solve(BlockedWorkspace* ws, long long ncells, const double* d_coef, const
     int gi = 0;
     for (const MfGroup& mg : P->groups) {  // launches of the two halves interleaved: both queues fill at the same pace
       ++gi;
-      for (int k = 0; k < nh; ++k) mf_group_step(ws, halves[k], mg, gi, d_info);
+      for (int k = 0; k < nh; ++k) mf_group_step(ws, P, halves[k], mg, gi, d_info);
     }
     const MfGroup& root = P->groups.back();
     for (int k = 0; k < nh; ++k) {
       const MfHalf& h = halves[k];
       hipLaunchKernelGGL(k_mf_finalize, dim3(nblk(h.nc * G.t * G.t)), dim3(256), 0, h.st, P->C0 + h.base * 36,
                          P->arena + h.base * P->arena_per_cell, root.offF, root.L, root.sp, root.rb, G.t, d_out + h.c0 * G.t * G.t, h.nc);
+    }
+    if (d_corr) {  // back substitution: root first; then the mean of every component goes (cell_problem.py:349-361, 382)
+      for (auto it = P->groups.rbegin(); it != P->groups.rend(); ++it)
+        for (int k = 0; k < nh; ++k) mf_backsub_step(ws, P, halves[k], *it, d_corr);
+      for (int k = 0; k < nh; ++k)
+        launch_center_corr(ws, d_corr + halves[k].c0 * G.t * (long long)G.nn * bs, halves[k].nc, halves[k].st);
     }
     if (nh == 2) {  // st continues (next chunk, the caller's work) when both halves are done
       MTRY(hipEventRecord(P->ev_join, P->side));

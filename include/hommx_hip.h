@@ -55,6 +55,8 @@ extern "C" {
  *                          elimination (default: 65, i.e. every plane block the one-launch kernels do not take; 100 for scalar 3D; 0: never)
  *   HOMMX_MF_STREAMS       1: the nested-dissection route runs on the caller's stream alone (default 2: the two halves of every chunk side
  *                          by side on the caller's stream and a plan-owned one; the caller's stream waits for both, results are bitwise equal)
+ *   HOMMX_MF_CORR          0: hommx_solve_batch_correctors of a nested-dissection plan runs the plane elimination (default: back substitution
+ *                          down the elimination tree on a second plan whose fronts all stay resident)
  *   HOMMX_MF_LEAF, HOMMX_MF_SPLIT_DEPTH, HOMMX_MF_G128_MIN_K, HOMMX_MF_NO_BORDER_SPLIT, HOMMX_MF_VERBOSE   tuning / A-B knobs of that route
  *   HOMMX_SMALL_WAVES      2 / 4: plane blocks b <= 48 take the LDS-resident multi-wave kernel (that many waves per macro cell)
  *                          instead of the one-wave-per-cell register kernel; for 48 < b <= 64 it sets that kernel's wave count

@@ -130,9 +130,9 @@ def test_production_size_agrees_with_the_plane_elimination():
 
 
 def test_correctors_on_the_same_plan_do_not_disturb_the_tensors(rng):
-    """Effective tensors come from the nested-dissection route, correctors from the plane elimination (hommx_solve_batch_correctors): one
-    plan serves both, with workspaces of different chunk sizes -- interleaved calls must not see each other's buffers, and the correctors'
-    Schur form reproduces the tensors of the other route."""
+    """Effective tensors and correctors of one plan come from two multifrontal plans (the corrector plan keeps every front for the back
+    substitution, hommx_solve_batch_correctors) with workspaces of different chunk sizes -- interleaved calls must not see each other's
+    buffers, and the corrector call returns the same tensors."""
     from hommx_amd import MicroCellPlan
 
     p = MicroCellPlan(3, 6, "elasticity")
@@ -140,11 +140,79 @@ def test_correctors_on_the_same_plan_do_not_disturb_the_tensors(rng):
     coef = rng.uniform(0.5, 3.0, size=(40, p.n_el, 2))
     M = np.eye(3)[None] + 0.2 * rng.standard_normal((40, 3, 3))
     A1 = p.solve(coef, M)
-    A2, chi = p.solve(coef[:3], M[:3], return_correctors=True)   # plane elimination, 3 cells: a much smaller workspace
-    A3 = p.solve(coef, M)                                        # 40 cells on the multifrontal route again
+    A2, chi = p.solve(coef[:3], M[:3], return_correctors=True)   # corrector plan, 3 cells: a much smaller workspace
+    A3 = p.solve(coef, M)                                        # 40 cells on the tensor plan again
     assert np.array_equal(A1, A3)
     assert np.abs(A2 - A1[:3]).max() <= 1e-11 * np.abs(A1).max()
     assert chi.shape == (3, 6, 6**3 * 3) and np.isfinite(chi).all()
+
+
+_CORR_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from hommx_amd import MicroCellPlan
+kind, dim, n, nc, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+rng = np.random.default_rng(11)
+p = MicroCellPlan(dim, n, kind)
+if kind == "poisson":
+    coef = np.exp(rng.uniform(np.log(0.1), np.log(5.0), size=(nc, p.n_el)))
+else:
+    coef = np.stack([rng.uniform(0.5, 2.0, (nc, p.n_el)), np.exp(rng.uniform(np.log(0.1), np.log(10.0), (nc, p.n_el)))], axis=-1)
+M = np.eye(dim)[None] + 0.3 * rng.standard_normal((nc, dim, dim))
+A, chi, info = p.solve(coef, M, return_info=True, return_correctors=True)
+np.savez(out, A=A, chi=chi, info=info, coef=coef, M=M, kernel=p.kernel)
+"""
+
+
+def _corr_child(kind, dim, n, nc, env):
+    import os, subprocess, sys, tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "c.npz")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _CORR_CHILD % {"root": root}, kind, str(dim), str(n), str(nc), f], check=True, env=e, timeout=900)
+        return dict(np.load(f))
+
+
+def _center(chi, bs):
+    x = chi.reshape(chi.shape[0], -1, bs)
+    return (x - x.mean(axis=1, keepdims=True)).reshape(chi.shape)
+
+
+@pytest.mark.parametrize("kind,dim,n,env", [
+    ("elasticity", 3, 5, {}),                                  # b = 75: the smallest 3D elasticity mesh of the route
+    ("elasticity", 3, 6, {"HOMMX_MF_STAGE": "64"}),            # several stages inside the fronts: the back substitution walks them backwards
+    ("poisson", 3, 10, {}),                                    # scalar 3D
+    ("poisson", 2, 72, {"HOMMX_MF_MIN_B": "65"}),              # 2D: narrow fronts
+    ("elasticity", 2, 36, {"HOMMX_MF_STREAMS": "1"}),          # one stream
+])
+def test_correctors_of_the_multifrontal_route_against_the_oracle(kind, dim, n, env):
+    """hommx_solve_batch_correctors on a multifrontal plan: back substitution down the elimination tree (multifrontal.hip) against the
+    oracle's correctors (hmm.py:397-432: K chi = b per load case, constants projected out) and, through the energy functional of the
+    reference (hmm.py:652-667 / 905-922), against the effective tensors of the same call.  33 cells: two halves on two streams."""
+    from oracle import hommx_oracle as O
+
+    r = _corr_child(kind, dim, n, 33, env)
+    assert str(r["kernel"]) == "multifrontal" and np.all(r["info"] == 0)
+    bs = 1 if kind == "poisson" else dim
+    for c in (0, 16, 17, 32):  # both halves
+        cp = O.build_cell_problem(kind, dim, n, r["coef"][c], r["M"][c])
+        chi = _center(O.solve_correctors(cp).T, bs)
+        assert np.abs(r["chi"][c] - chi).max() < 1e-9 * np.abs(chi).max(), (c, np.abs(r["chi"][c] - chi).max() / np.abs(chi).max())
+        AH = O.effective_tensor(cp, r["chi"][c].T, form="energy")
+        assert np.abs(AH - r["A"][c]).max() < 1e-10 * np.abs(r["A"][c]).max()
+
+
+def test_correctors_of_the_two_eliminations_agree_at_the_production_size():
+    """16^3 elasticity cells (12,288 unknowns, BASELINE C4 / C5 size): correctors of the multifrontal route == correctors of the plane
+    elimination (HOMMX_MF_CORR=0) on the same inputs."""
+    a = _corr_child("elasticity", 3, 16, 3, {})
+    b = _corr_child("elasticity", 3, 16, 3, {"HOMMX_MF_CORR": "0"})
+    assert np.all(a["info"] == 0) and np.all(b["info"] == 0)
+    assert np.abs(a["A"] - b["A"]).max() <= 1e-10 * np.abs(b["A"]).max()
+    assert np.abs(a["chi"] - b["chi"]).max() <= 1e-8 * np.abs(b["chi"]).max(), np.abs(a["chi"] - b["chi"]).max() / np.abs(b["chi"]).max()
 
 
 def test_stratified_elasticity_solver_class_on_the_multifrontal_route():
