@@ -949,10 +949,11 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   ws->split64 = getenv("HOMMX_NO_SPLIT64") == nullptr;
   ws->small_fused = getenv("HOMMX_NO_SMALL_FUSED") == nullptr;
   if (const char* e = getenv("HOMMX_SMALL_WAVES")) ws->small_waves = atoi(e);
-  // route: nested dissection (multifrontal.hip) wherever it beats the plane elimination (profiles/r03_kinds_routes.txt): every plane
-  // block b > 64 except scalar 3D problems below b = 100 (n = 9: -10 %; n = 10: +20 %) -- 2D scalar n = 80: +51 %, 2D elasticity n = 36:
-  // +92 %, 3D elasticity n = 5: +68 %, n = 16: +76 %
-  ws->mf_min_b = (G.dim == 3 && G.bs == 1) ? 100 : 65;
+  // route: nested dissection (multifrontal.hip) wherever it beats the plane elimination (profiles/r03_kinds_routes.txt) -- every plane
+  // block b > 64, i.e. everything the one-launch kernels do not take: 2D scalar n = 80: +51 %, 2D elasticity n = 36: +92 %, 3D elasticity
+  // n = 5: +68 %, n = 16: +76 %, scalar 3D n = 9: +18 % (it lost 10 % there before the build kernel batched its loads and the route ran on
+  // two streams)
+  ws->mf_min_b = 65;
   if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
   if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
   ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;

@@ -52,7 +52,7 @@ extern "C" {
  *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the one-launch kernels
  *   HOMMX_MF_MIN_B         smallest plane block b routed to the nested-dissection (multifrontal) elimination instead of the plane
- *                          elimination (default: 65, i.e. every plane block the one-launch kernels do not take; 100 for scalar 3D; 0: never)
+ *                          elimination (default: 65, i.e. every plane block the one-launch kernels do not take; 0: never)
  *   HOMMX_MF_STREAMS       1: the nested-dissection route runs on the caller's stream alone (default 2: the two halves of every chunk side
  *                          by side on the caller's stream and a plan-owned one; the caller's stream waits for both, results are bitwise equal)
  *   HOMMX_MF_CORR          0: hommx_solve_batch_correctors of a nested-dissection plan runs the plane elimination (default: back substitution

@@ -1,6 +1,6 @@
 """Nested-dissection route of the blocked family (csrc/multifrontal.hip; -m gpu): the same micro problems as the plane elimination
 (forms /root/reference/src/hommx/hmm.py:644-667 / 759-789 / 887-922 / 1024-1067 on the periodic unit cell, cell_problem.py:38-300),
-another elimination order.  The route is chosen when the plan is created (plane block b >= HOMMX_MF_MIN_B, default 192), hence the child
+another elimination order.  The route is chosen when the plan is created (plane block b >= HOMMX_MF_MIN_B, default 65: every block the one-launch kernels do not take), hence the child
 processes for the forced / disabled variants."""
 import os
 import subprocess
