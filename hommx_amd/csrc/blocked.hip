@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../include/hommx_hip.h"
 #include "blocked_internal.h"
@@ -958,6 +959,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
   ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;
   if (const char* e = getenv("HOMMX_MF_CORR")) ws->mf_corr = atoi(e) != 0;
+  if (const char* e = getenv("HOMMX_TILE_SB")) ws->tile_sb = atoi(e);
   if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && (G.b > 64 || !ws->small_fused)) {
     if (int rc = mf_plan_create(&ws->mf, G)) {
       delete ws;
@@ -1009,6 +1011,7 @@ void blocked_workspace_destroy(BlockedWorkspace* ws) {
   if (!ws) return;
   if (ws->mf) mf_plan_destroy(ws->mf);
   if (ws->mf_keep) mf_plan_destroy(ws->mf_keep);
+  for (auto& kv : ws->tilemaps) (void)hipFree(kv.second);
   ws_free(ws);
   delete ws;
 }
@@ -1086,7 +1089,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
                                                     int lda, long long sA, const double* __restrict__ B, int ldb,
                                                     long long sB, double beta, double* __restrict__ C, int ldc,
                                                     long long sC, int lowerOnly, int nc, int tilesX, int tilesPerCell,
-                                                    double* Ct, GatherC ga = GatherC()) {
+                                                    double* Ct, GatherC ga = GatherC(), const int* __restrict__ tilemap = nullptr) {
   constexpr int PITCH = TM + 16;  // 2 PITCH dwords == 32 mod 64 for TM = 64 and 128: conflict-free ds_read_b64 fragments
   constexpr int WTM = TM / 2, WTN = TM / (NW / 2);  // per-wave tile: waves form a 2 x (NW / 2) grid
   constexpr int NFA = WTM / 16, NFB = WTN / 16;     // 16x16 MFMA tiles per wave, rows / columns
@@ -1098,7 +1101,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
   if (cell >= nc) return;
   const int tile = slot % tilesPerCell;
   int ty, tx;
-  if (lowerOnly) {  // tiles of the lower triangle, row by row
+  if (tilemap) {  // lower triangle in super-blocks (gemm): the panels of a block stay in the XCD's L2
+    ty = tilemap[tile] >> 16;
+    tx = tilemap[tile] & 0xffff;
+  } else if (lowerOnly) {  // tiles of the lower triangle, row by row
     ty = 0;
     while ((ty + 1) * (ty + 2) / 2 <= tile) ++ty;
     tx = tile - ty * (ty + 1) / 2;
@@ -1289,6 +1295,27 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
       return;
     }
   }
+  // Big lower-triangle updates walk their tiles in SB x SB super-blocks: row by row a tile row of a 1,536-front touches 8 MB of B panels,
+  // twice an XCD's L2, and every panel is fetched once per tile (the rank-672 update of C4 fetched 143 MB per cell for 52 MB of operands)
+  const int* tilemap = nullptr;
+  if (lowerOnly && c.ws->tile_sb > 1 && ty >= 2 * c.ws->tile_sb) {
+    auto it = c.ws->tilemaps.find(ty);
+    if (it == c.ws->tilemaps.end()) {
+      const int SB = c.ws->tile_sb;
+      std::vector<int> order;
+      order.reserve(T);
+      for (int I = 0; I < ty; I += SB)
+        for (int J = 0; J <= I; J += SB)
+          for (int i = I; i < std::min(I + SB, ty); ++i)
+            for (int j = J; j < std::min(J + SB, ty) && j <= i; ++j) order.push_back(i << 16 | j);
+      int* d = nullptr;
+      if (hipMalloc(&d, sizeof(int) * order.size()) == hipSuccess &&
+          hipMemcpy(d, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice) == hipSuccess)
+        it = c.ws->tilemaps.emplace(ty, d).first;
+      else if (d) (void)hipFree(d);
+    }
+    if (it != c.ws->tilemaps.end()) tilemap = it->second;
+  }
   dim3 grid((unsigned)(groups * 8 * T));
   // 128 tiles: 8 waves per workgroup (2 x 4 grid of 64 x 32 wave tiles, 110 VGPRs, 4 waves per SIMD): +2 % over 4 waves
   // of 64 x 64; 64 tiles: 4 waves of 32 x 32 (8 waves measured slower)
@@ -1296,18 +1323,18 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
   do {                                                                                                                      \
     if (big)                                                                                                                \
       hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 128, 8>), grid, dim3(512), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB,   \
-                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, GatherC());                                     \
+                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, GatherC(), tilemap);                            \
     else                                                                                                                    \
       hipLaunchKernelGGL((k_gemm_tile<TA_, TB_, 64, 4>), grid, dim3(256), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB,    \
-                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, GatherC());                                     \
+                         beta, C, ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, GatherC(), tilemap);                            \
   } while (0)
   if (gather) {  // virtual C (multifrontal.hip): NN only
     if (big)
       hipLaunchKernelGGL((k_gemm_tile<false, false, 128, 8, true>), grid, dim3(512), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C,
-                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, *gather);
+                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, *gather, tilemap);
     else
       hipLaunchKernelGGL((k_gemm_tile<false, false, 64, 4, true>), grid, dim3(256), 0, c.st, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C,
-                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, *gather);
+                         ldc, sC, lowerOnly, (int)c.nc, tx, T, Ct, *gather, tilemap);
     return;
   }
   if (!ta && !tb) HOMMX_GT(false, false);

