@@ -236,11 +236,17 @@ int hommx_solve_batch(hommx_plan* p, int64_t n_cells, const double* coef, const 
   }
   if (M) HIP_TRY(hipMemcpy(p->d_M, M, sizeof(double) * n_cells * d * d, hipMemcpyHostToDevice));
   const int64_t per = p->n_el * p->n_comp;
-  constexpr int64_t CH = 2048;  // cells per chunk: one wave per cell fills the 256 CUs x 8 wave slots exactly once
-  if (p->family == FAM_FUSED2D && n_cells >= 2 * CH && p->h2d_overlap) {
-    // The coefficient stream (16 KiB per cell) costs more PCIe time than the kernel costs GPU time: pipeline it.  The
-    // copies are issued from pageable memory, so each blocks this thread -- while the kernel of the previous chunk,
-    // already queued on the other stream, runs.
+  // cells per chunk of the pipelined copy.  Fused 2D kernel: one wave per cell fills the 256 CUs x 8 wave slots exactly once; blocked
+  // family: about 256 MB of coefficient stream, at least 256 cells (from there its throughput is flat: C4 / C5 393 KB per cell -> 682)
+  int64_t CH = 2048;
+  if (p->family != FAM_FUSED2D) {
+    CH = (int64_t)((256ll << 20) / (8 * (per > 0 ? per : 1)));
+    CH = CH < 256 ? 256 : CH > 4096 ? 4096 : CH;
+  }
+  if (n_cells >= 2 * CH && p->h2d_overlap) {
+    // The coefficient stream (16 KiB per 2D cell, 393 KB per 16^3 elasticity cell) costs PCIe time -- more than the fused kernel costs GPU
+    // time, 4 - 8 % of the 3D solves: pipeline it.  The copies are issued from pageable memory, so each blocks this thread -- while the
+    // kernels of the previous chunk, already queued on the other stream, run.
     if (!p->s_copy) {
       HIP_TRY(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
