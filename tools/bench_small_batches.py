@@ -1,4 +1,5 @@
-"""Dev tool: small batches of the nested-dissection route, plain launches against hipGraph replay (HOMMX_MF_GRAPH=0 / default).
+"""Dev tool: small, launch-bound batches of the nested-dissection route (20 repeated device-pointer calls with the same arguments; it
+timed plain launches against a hipGraph replay, which was slower and is not in the tree: DESIGN.md 4.4).
     python tools/bench_small_batches.py dim n kind cells [cells ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
