@@ -231,9 +231,9 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
   tb.dim = dim;
   tb.n = n;
   // leaves of about 64 - 81 unknowns (a leaf front pads its eliminated block to a multiple of 32): 27 nodes x 3 unknowns for 3D elasticity
-  // (12 and 64 nodes measure the same within 1 %), 64 nodes for scalar problems (3D 16^3: +10 %, 2D 128^2: +69 % over 9-node leaves),
-  // 32 for two unknowns per node
-  tb.leaf_max = bs >= 3 ? 27 : bs == 2 ? 32 : 64;
+  // (12 and 64 nodes measure the same within 1 %), 64 nodes for scalar 3D problems (16^3: +10 % over 9-node leaves), 32 for two unknowns
+  // per node (16: the same); scalar 2D: 25 (against 64: 80^2 +10 %, 96^2 +6 %, 128^2 +3 %; 16: -30 %)
+  tb.leaf_max = bs >= 3 ? 27 : bs == 2 ? 32 : dim == 2 ? 25 : 64;
   if (const char* e = getenv("HOMMX_MF_LEAF")) tb.leaf_max = std::max(1, atoi(e));
   if (const char* e = getenv("HOMMX_MF_SPLIT_DEPTH")) tb.split_depth = atoi(e);
   if (const char* e = getenv("HOMMX_MF_STAGE")) P->stage = atoi(e);
