@@ -45,7 +45,8 @@ extern "C" {
 /* Environment knobs (development / tuning; read once, when a plan is created):
  *   HOMMX_BLOCKED_MEM_GB   workspace budget of the blocked family in GB (default: plane elimination min(64, half of the free HBM),
  *                          nested dissection min(64 -- 128 through hommx_plan_reserve --, 0.6 x free HBM): its fronts are 0.2 GB per C4 / C5 cell)
- *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256)
+ *   HOMMX_GEMM128_MIN      smallest M, N routed to the 128x128-tile GEMM (default 256 on the plane elimination; nested-dissection plans
+ *                          use the 64x64 tiles throughout)
  *   HOMMX_TILE_SB          big lower-triangle updates walk their tiles in SB x SB super-blocks (default 4; 0: row by row)
  *   HOMMX_SPARSE_V1        any value: generic instead of strip-form sparse E products
  *   HOMMX_LEAF32           any value: 32x32 leaves only in the recursive block inverse
