@@ -23,7 +23,7 @@
 //     index maps (GatherC epilogue of k_gemm_tile) and writes the front's update matrix once.  Only F11 / F21 (the eliminated columns)
 //     are written by k_mf_build: stencil entries + the children's entries, every entry exactly once -- no memset, no atomics.
 //   * Nodes are numbered in elimination order everywhere, so child -> parent maps are monotone and only lower triangles are ever needed.
-//   * The two halves of every chunk of cells run side by side on two streams (the caller's and a plan-owned one, mf_solve).
+//   * Every chunk of cells runs as two to four pieces side by side on as many streams (the caller's and plan-owned ones, mf_solve).
 // Gauge: the last node is pinned in the root front (cell_problem.py:349-361).
 #include <hip/hip_runtime.h>
 
@@ -80,10 +80,10 @@ struct MfPlan {
   long long chunk = 0;
   double *arena = nullptr, *scratch = nullptr, *vbuf = nullptr;
   double *Kst = nullptr, *Brhs = nullptr, *C0 = nullptr;  // K1 output of this route's chunks (the plane elimination keeps its own)
-  // second stream of mf_solve: a chunk runs as two halves side by side (HOMMX_MF_STREAMS = 1: off)
-  int streams = 2;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // side streams of mf_solve: a chunk runs as up to four pieces side by side (HOMMX_MF_STREAMS = 1: off, 2 .. 4)
+  int streams = 4;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 
 constexpr int MF_BORDER = 8;  // load rows per front (t <= 6)
@@ -215,9 +215,11 @@ void mf_plan_destroy(MfPlan* p) {
   }
   for (double* q : {p->arena, p->scratch, p->vbuf, p->Kst, p->Brhs, p->C0})
     if (q) (void)hipFree(q);
-  if (p->side) (void)hipStreamDestroy(p->side);
+  for (int k = 0; k < 3; ++k) {
+    if (p->side[k]) (void)hipStreamDestroy(p->side[k]);
+    if (p->ev_join[k]) (void)hipEventDestroy(p->ev_join[k]);
+  }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
 }
 
@@ -864,29 +866,35 @@ int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_
     const long long nchunks = (ncells + step_cells - 1) / step_cells;
     step_cells = (ncells + nchunks - 1) / nchunks;
   }
-  // The two halves of a chunk run side by side on two streams (each owns half of the chunk buffers): small launches of one half fill
-  // the tails of the other's, and memory-bound and matrix-core-bound waves share the CUs.  3D elasticity 8^3: +11 %, scalar 3D 16^3: +8 %,
-  // 2D 128^2: +9 %, C4: +2 %; running the second stream a few groups behind, or four pieces per chunk, gains nothing more.  The
-  // arithmetic of a cell does not depend on the batch it is in: results are bitwise the same.
-  const bool two = P->streams >= 2 && step_cells >= 16;
-  if (two && !P->side) {
-    MTRY(hipStreamCreateWithFlags(&P->side, hipStreamNonBlocking));
+  // A chunk runs as two to four pieces side by side on as many streams (each owns its share of the chunk buffers): small launches of
+  // one piece fill the tails of the others', and memory-bound and matrix-core-bound waves share the CUs.  Two streams against one: 3D
+  // elasticity 8^3 +11 %, scalar 3D 16^3 +8 %, 2D 128^2 +9 %, C4 +2 %; four against two (pieces of at least 128 cells): all of C5 +2 %,
+  // scalar 3D 16^3 +5 %; running the second stream a few groups behind gains nothing more.  The arithmetic of a cell does not depend on
+  // the batch it is in: results are bitwise the same.
+  const int want = std::max(1, std::min(4, P->streams));
+  const bool two = want >= 2 && step_cells >= 16;
+  if (two && !P->ev_fork) {
+    for (int k = 0; k + 1 < want; ++k) {
+      MTRY(hipStreamCreateWithFlags(&P->side[k], hipStreamNonBlocking));
+      MTRY(hipEventCreateWithFlags(&P->ev_join[k], hipEventDisableTiming));
+    }
     MTRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
-    MTRY(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
   }
   const int bs = G.bs;
   for (long long c0 = 0; c0 < ncells; c0 += step_cells) {
     const long long nc = std::min(step_cells, ncells - c0);
-    MfHalf halves[2];
+    MfHalf halves[4];
     int nh = 1;
     halves[0] = MfHalf{c0, nc, 0, st};
     if (two && nc >= 2) {
-      const long long na = (nc + 1) / 2;
-      halves[0].nc = na;
-      halves[1] = MfHalf{c0 + na, nc - na, na, P->side};
-      nh = 2;
-      MTRY(hipEventRecord(P->ev_fork, st));  // the side stream starts behind everything queued on st (inputs, the previous chunk)
-      MTRY(hipStreamWaitEvent(P->side, P->ev_fork, 0));
+      nh = (int)std::max(2ll, std::min<long long>(want, nc / 128));  // pieces of at least 128 cells beyond two
+      const long long per = (nc + nh - 1) / nh;
+      for (int k = 0; k < nh; ++k) {
+        const long long a = std::min(nc, k * per), b = std::min(nc, (k + 1) * per);
+        halves[k] = MfHalf{c0 + a, b - a, a, k == 0 ? st : P->side[k - 1]};
+      }
+      MTRY(hipEventRecord(P->ev_fork, st));  // the side streams start behind everything queued on st (inputs, the previous chunk)
+      for (int k = 1; k < nh; ++k) MTRY(hipStreamWaitEvent(P->side[k - 1], P->ev_fork, 0));
     }
     for (int k = 0; k < nh; ++k) {
       const MfHalf& h = halves[k];
@@ -894,7 +902,7 @@ int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_
                       P->Kst + h.base * G.ncode * bs * bs * G.nn, P->Brhs + h.base * G.t * bs * G.nn, P->C0 + h.base * 36);
     }
     int gi = 0;
-    for (const MfGroup& mg : P->groups) {  // launches of the two halves interleaved: both queues fill at the same pace
+    for (const MfGroup& mg : P->groups) {  // launches of the pieces interleaved: all queues fill at the same pace
       ++gi;
       for (int k = 0; k < nh; ++k) mf_group_step(ws, P, halves[k], mg, gi, d_info);
     }
@@ -910,9 +918,9 @@ int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_
       for (int k = 0; k < nh; ++k)
         launch_center_corr(ws, d_corr + halves[k].c0 * G.t * (long long)G.nn * bs, halves[k].nc, halves[k].st);
     }
-    if (nh == 2) {  // st continues (next chunk, the caller's work) when both halves are done
-      MTRY(hipEventRecord(P->ev_join, P->side));
-      MTRY(hipStreamWaitEvent(st, P->ev_join, 0));
+    for (int k = 1; k < nh; ++k) {  // st continues (next chunk, the caller's work) when every piece is done
+      MTRY(hipEventRecord(P->ev_join[k - 1], P->side[k - 1]));
+      MTRY(hipStreamWaitEvent(st, P->ev_join[k - 1], 0));
     }
     MTRY(hipGetLastError());
   }

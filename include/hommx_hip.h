@@ -55,8 +55,8 @@ extern "C" {
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the one-launch kernels
  *   HOMMX_MF_MIN_B         smallest plane block b routed to the nested-dissection (multifrontal) elimination instead of the plane
  *                          elimination (default: 65, i.e. every plane block the one-launch kernels do not take; 0: never)
- *   HOMMX_MF_STREAMS       1: the nested-dissection route runs on the caller's stream alone (default 2: the two halves of every chunk side
- *                          by side on the caller's stream and a plan-owned one; the caller's stream waits for both, results are bitwise equal)
+ *   HOMMX_MF_STREAMS       1: the nested-dissection route runs on the caller's stream alone (default 4: every chunk as two to four pieces side
+ *                          by side on the caller's stream and plan-owned ones; the caller's stream waits for all, results are bitwise equal)
  *   HOMMX_MF_CORR          0: hommx_solve_batch_correctors of a nested-dissection plan runs the plane elimination (default: back substitution
  *                          down the elimination tree on a second plan whose fronts all stay resident)
  *   HOMMX_MF_LEAF, HOMMX_MF_SPLIT_DEPTH, HOMMX_MF_G128_MIN_K, HOMMX_MF_NO_BORDER_SPLIT, HOMMX_MF_VERBOSE   tuning / A-B knobs of that route
