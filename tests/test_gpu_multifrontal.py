@@ -98,6 +98,41 @@ def test_bad_cells_are_flagged_and_do_not_leak_and_chunks_do_not_change_bits():
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_pieces_on_one_to_four_streams_give_the_same_bits():
+    """A chunk runs as two to four pieces side by side on as many streams (mf_solve; HOMMX_MF_STREAMS = 1: the caller's stream alone).
+    520 cells of a 5^3 elasticity mesh: four pieces by default -- bitwise the tensors of one stream, with a bad cell in the third piece
+    flagged and nothing else touched, and four sampled cells against the oracle."""
+    code = f"""
+        import sys; sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        rng = np.random.default_rng(5)
+        p = MicroCellPlan(3, 5, "elasticity")
+        assert p.kernel == "multifrontal"
+        coef = rng.uniform(0.5, 3.0, size=(520, p.n_el, 2))
+        coef[300] = -1.0
+        M = np.eye(3)[None] + 0.2 * rng.standard_normal((520, 3, 3))
+        A, info = p.solve(coef, M, return_info=True)
+        assert info[300] > 0 and (info != 0).sum() == 1, np.nonzero(info)
+        np.savez(sys.argv[1], A=A, coef=coef[[0, 131, 262, 519]], M=M[[0, 131, 262, 519]])
+        print("ok")
+    """
+    outs = []
+    for streams in ("4", "1"):
+        f = os.path.join("/tmp", f"hommx_mf_streams_{streams}_{os.getpid()}.npz")
+        _child(code.replace("sys.argv[1]", repr(f)), {"HOMMX_MF_STREAMS": streams})
+        outs.append(dict(np.load(f)))
+        os.remove(f)
+    keep = np.arange(520) != 300
+    assert np.array_equal(outs[0]["A"][keep], outs[1]["A"][keep])
+    sys.path.insert(0, ROOT)
+    from oracle import hommx_oracle as O
+
+    ref = O.effective_tensor_batch("elasticity", 3, 5, outs[0]["coef"], outs[0]["M"])
+    got = outs[0]["A"][[0, 131, 262, 519]]
+    assert np.abs(got - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 def test_production_size_agrees_with_the_plane_elimination():
     """16^3 micro cells, three unknowns per node: the two eliminations of the blocked family on the SAME cells (C4 fibre contrast 1e5 and
     moderate random media) -- different orders of 12,288 unknowns, results equal to rounding."""
