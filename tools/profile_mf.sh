@@ -39,8 +39,9 @@ tot_ns = sum(float(r[2]) for r in rows[1:] if fam(r[0]))
 res = {"command": f"tools/profile_mf.sh {tag} {cells}: rocprofv3 (kernel trace; then --pmc SQ set, FETCH_SIZE, WRITE_SIZE in separate passes) -- "
                   f"python3 tools/mf_check.py --time-only {cells}  (3D elasticity, 16^3 micro cells, two solves of {cells} cells)",
        "cells_per_solve": cells, "kernel_time_ms_per_solve": tot_ns / 2e6,
-       "note": "the route runs the two halves of a chunk side by side on two streams (HOMMX_MF_STREAMS=1: one): kernel durations overlap, "
-               "so their sum (kernel_time_ms_per_solve, time_us_per_cell) is about twice the wall clock; shares and counters are unaffected",
+       "note": "the route runs two to four pieces of a chunk side by side on as many streams (HOMMX_MF_STREAMS=1: one): kernel durations "
+               "overlap, so their sum (kernel_time_ms_per_solve, time_us_per_cell) is several times the wall clock and small serial kernels "
+               "stretch most; counters are unaffected",
        "families": {}}
 for f, a in agg.items():
     t_ns = sum(float(r[2]) for r in rows[1:] if fam(r[0]) == f)
