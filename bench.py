@@ -15,10 +15,15 @@ A "step" is one pass of the hot path over one batch of synthetic input.
   rotated-fibre theta.  The 24,576 cells are block-partitioned over the N ranks (STRONG scaling); every rank samples only its
   own shard (two phase values + M per cell; the fibre mask once), solves it and the C_H field is all-gathered over RCCL.
 
-Prints ONE JSON line on rank 0 (contract: metric/value/unit/..., plus `roofline` and `cpu_baseline`).  Beside the
-device-resident `value` the line carries, for C2 at N = 1: `value_host_boundary` (hommx_solve_batch on pageable host arrays:
-H2D of the 134 MB coefficient stream + kernel + D2H, what SURVEY 8(d) calls a solve), `value_two_phase` (the on-device sampler:
-2 KB mask + 16 B per cell in) -- neither is `value`.
+Prints ONE JSON line on rank 0 (contract: metric/value/unit/..., plus `roofline` and `cpu_baseline`).
+
+`value` is the device-resident rate the bench contract asks for (inputs in HBM when the timed region starts; equal to
+`value_device_resident`).  SURVEY 8(d) defines the unit of work WITH the transfers ("H2D of inputs and D2H of A_eff included"): that
+figure is `value_survey_8d` -- the C-ABI call `hommx_solve_batch_two_phase` on HOST arrays, C2's own coefficient shape (a 2 KB phase
+mask + two values per macro cell in, A_H + info out, one synchronisation) -- and `value_host_boundary` is the generic 134 MB element
+stream through `hommx_solve_batch` (PCIe-bound).  The default C2 line also carries a nested `"c5"` record (BASELINE config 5: the 3D
+stratified-elasticity path on the nested-dissection route, all 24,576 cells, `--c5-steps` timed passes with the workspace reserved
+outside the timed region) with its own `roofline` and `cpu_baseline`; `--no-c5` leaves it out.
 """
 
 from __future__ import annotations
@@ -36,6 +41,7 @@ sys.path.insert(0, HERE)
 
 FP64_PEAK_DATASHEET = 78.6e12  # FLOP/s, AMD MI355X datasheet: FP64 vector == FP64 matrix (absent from the local guide)
 PMC_SUMMARY = os.path.join("profiles", "r03_c2_pmc_summary.json")
+MF_PMC_SUMMARY = os.path.join("profiles", "r03_mf_pmc_summary.json")
 
 
 def flop_model(n: int, b: int | None = None) -> float:
@@ -129,7 +135,7 @@ def cpu_baseline_c5(shape, n: int, cells: np.ndarray):
     return len(cells) / dt, len(cells)
 
 
-def cpu_baseline_c5_multicore(args, n_sample: int):
+def cpu_baseline_c5_multicore(args, n_sample: int, n: int):
     """"C4/C5 CPU: time a fixed subsample (first 8 cells) and extrapolate linearly".  One cell per process, side by
     side; rate = cells / the slowest worker's time."""
     import subprocess
@@ -138,7 +144,7 @@ def cpu_baseline_c5_multicore(args, n_sample: int):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--config", "C5", "--cpu-worker", str(w), "1", "--micro",
-                              str(args.micro), "--c5-shape"] + [str(v) for v in args.c5_shape], stdout=subprocess.PIPE, text=True, env=env)
+                              str(n), "--c5-shape"] + [str(v) for v in args.c5_shape], stdout=subprocess.PIPE, text=True, env=env)
             for w in range(n_sample)]
     done, slowest = 0, 0.0
     for k in kids:
@@ -285,14 +291,26 @@ def dry_run(args):
         b, e, ntot, t, scaling = rank * per, (rank + 1) * per, world * per, 2, "weak"
     out = torch.zeros(per, t, t, dtype=torch.float64)
     out[: e - b] = float(rank + 1)
-    field = all_gather_field(out, world * per) if use_dist else out
-    owners = sorted({int(v) for v in field[:, 0, 0].tolist() if v > 0})
+    t0 = time.perf_counter()
+    if use_dist and args.config == "C5":  # the product's unpadding (dist._unpad_index): ragged shards, ranks that own nothing
+        from hommx_amd.dist import _unpad_index
+
+        field = all_gather_field(out, world * per)[torch.from_numpy(_unpad_index(ntot, per, world))]
+    else:
+        field = all_gather_field(out, world * per) if use_dist else out
+    ag_ms = (time.perf_counter() - t0) * 1e3 if use_dist else None
+    owner = [int(v) for v in field[:, 0, 0].tolist()]
+    owners = sorted({v for v in owner if v > 0})
     if rank == 0:
-        print(json.dumps({"metric": "micro-cell solves/sec", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": scaling,
-                          "vs_baseline": None, "dtype": "f64", "data": "dry-run", "dry_run": True,
-                          "config": {"workload": f"{args.config} launcher rehearsal on gloo, no kernel", "cells_total": ntot},
-                          "ranks_seen_in_gathered_field": owners}), flush=True)
+        rec = {"metric": "micro-cell solves/sec", "value": None, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": scaling,
+               "vs_baseline": None, "dtype": "f64", "data": "dry-run", "dry_run": True, "allgather_ms": ag_ms,
+               "config": {"workload": f"{args.config} launcher rehearsal on gloo, no kernel", "cells_total": ntot},
+               "ranks_seen_in_gathered_field": owners}
+        if args.config == "C5":
+            rec["cells_per_rank"] = [shard_range(ntot, r, world)[1] - shard_range(ntot, r, world)[0] for r in range(world)]
+            rec["owner_of_cell"] = owner
+        print(json.dumps(rec), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
@@ -333,6 +351,9 @@ def main():
     ap.add_argument("--macro", type=int, default=64, help="C2: macro cells per side (64)")
     ap.add_argument("--micro", type=int, default=None, help="micro cells per side (C2: 32, C5: 16)")
     ap.add_argument("--c5-shape", type=int, nargs=3, default=(32, 16, 8), help="C5: macro box (32 16 8 = 24,576 tets)")
+    ap.add_argument("--no-c5", action="store_true", help="C2: leave the nested C5 record (3D elasticity path) out of the line")
+    ap.add_argument("--c5-steps", type=int, default=2, help="C2: timed passes over all 24,576 C5 cells in the nested record (about 9 s each on one GPU)")
+    ap.add_argument("--c5-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-boundary and two-phase figures")
     ap.add_argument("--cpu-cores", type=int, default=0, help="host cores for the CPU baseline (0: min(16, available))")
@@ -431,6 +452,17 @@ def main():
     dt, kern_ms, ag_ms, field = timed_steps(step, args.steps, args.warmup, use_dist, dist, dev, torch)
     n_bad = int((info != 0).sum().item())
 
+    # nested record of BASELINE config 5 (the 3D elasticity path): every rank takes part (strong scaling of the 24,576 cells)
+    c5 = None
+    if not args.no_c5:
+        try:
+            c5 = run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellPlan, workloads, all_gather_field,
+                        shard_range, stream, steps=args.c5_steps, warmup=args.c5_warmup, n=16)
+        except Exception as exc:  # the C2 line must not be lost to a failure of the nested run; run_c5 made the ranks agree on it
+            print(f"[bench] nested C5 record failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+            c5 = {"error": f"{type(exc).__name__}: {exc}"}
+        stream = torch.cuda.current_stream()
+
     if rank == 0:
         value = world * nc * args.steps / dt
         flops = flop_model(n) * nc
@@ -482,6 +514,11 @@ def main():
             },
             "info_nonzero": n_bad,
         }
+        rec["value_device_resident"] = value
+        rec["value_note"] = ("`value` = device-resident rate (bench contract: inputs in HBM when the timed region starts); SURVEY 8(d)'s unit of work "
+                             "includes H2D of the inputs and D2H of A_eff: `value_survey_8d`")
+        if c5 is not None:
+            rec["c5"] = c5
         # HBM traffic per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit in
         # one pass and must not be mixed with tracing), so the figure comes from the committed summary of exactly this
         # command (FETCH_SIZE x 2 as the hardware guide prescribes on gfx950 for 16 B/lane reads, + WRITE_SIZE)
@@ -543,6 +580,10 @@ def main():
                 call_tp()
             tp = (time.perf_counter() - t0) / reps_tp
             rec["value_two_phase"] = nc / tp
+            rec["value_survey_8d"] = nc / tp
+            rec["value_survey_8d_note"] = ("SURVEY 8(d) unit of work, transfers included: hommx_solve_batch_two_phase on HOST arrays (C2's own coefficient "
+                                           "shape: 2 KB phase mask + two values per macro cell in, A_H + info out, one synchronisation), mean of "
+                                           f"{reps_tp} calls")
             rec["two_phase_ms"] = tp * 1e3
             rec["two_phase_over_kernel"] = tp * 1e3 / kern_ms
             rec["two_phase_bitwise_equal_to_stream"] = bool(np.array_equal(A_tp, A_host))
@@ -602,21 +643,40 @@ def main():
 
 
 def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellPlan, workloads, all_gather_field, shard_range,
-           stream):
-    """BASELINE config 5: strong scaling of the 24,576 stratified 3D elasticity cells over the ranks."""
-    n = args.micro
+           stream, steps=None, warmup=None, n=None):
+    """BASELINE config 5: strong scaling of the 24,576 stratified 3D elasticity cells over the ranks.  Returns the record on rank 0
+    (None elsewhere).  Under a process group the ranks agree that every one of them got through its set-up (plan, workspace, inputs)
+    BEFORE the first collective of the timed loop: a rank that failed there makes all of them raise instead of leaving the others
+    waiting in an all-gather."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    n = args.micro if n is None else n
     shape = tuple(args.c5_shape)
     ntot = 6 * shape[0] * shape[1] * shape[2]
     b, e, per = shard_range(ntot, rank, world)
     cells = np.arange(b, e)
-    _, mask_h, values_h, M_h = workloads.c5_two_phase(shape, n, cells=cells)  # this rank's shard only
-    plan = MicroCellPlan(3, n, "elasticity", device=local_rank)
-    plan.reserve(e - b)  # the workspace (fronts of a chunk of cells) is part of the plan, not of a timed step
-    mask = torch.from_numpy(mask_h.astype(np.uint8)).to(dev)
-    values = torch.from_numpy(values_h).to(dev)
-    M = torch.from_numpy(M_h).to(dev)
-    out = torch.zeros(per, 6, 6, dtype=torch.float64, device=dev)  # padded shard
-    info = torch.zeros(per, dtype=torch.int32, device=dev)
+    setup_error = None
+    try:
+        _, mask_h, values_h, M_h = workloads.c5_two_phase(shape, n, cells=cells)  # this rank's shard only
+        plan = MicroCellPlan(3, n, "elasticity", device=local_rank)
+        t_res = time.perf_counter()
+        plan.reserve(e - b)  # the workspace (fronts of a chunk of cells) is part of the plan, not of a timed step
+        torch.cuda.synchronize()
+        reserve_s = time.perf_counter() - t_res
+        mask = torch.from_numpy(mask_h.astype(np.uint8)).to(dev)
+        values = torch.from_numpy(values_h).to(dev)
+        M = torch.from_numpy(M_h).to(dev)
+        out = torch.zeros(per, 6, 6, dtype=torch.float64, device=dev)  # padded shard
+        info = torch.zeros(per, dtype=torch.int32, device=dev)
+    except Exception as exc:  # noqa: BLE001 - agreed on below
+        setup_error = exc
+    if use_dist:
+        flag = torch.tensor([0.0 if setup_error is None else 1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0 and setup_error is None:
+            setup_error = RuntimeError("C5 set-up failed on another rank")
+    if setup_error is not None:
+        raise setup_error
     nloc = e - b
 
     def step(ev=None):
@@ -634,8 +694,12 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
             return full
         return out
 
-    dt, kern_ms, ag_ms, field = timed_steps(step, args.steps, args.warmup, use_dist, dist, dev, torch)
+    dt, kern_ms, ag_ms, field = timed_steps(step, steps, warmup, use_dist, dist, dev, torch)
     n_bad = int((info != 0).sum().item())
+    if use_dist:
+        nb = torch.tensor([float(n_bad)], dtype=torch.float64, device=dev)
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+        n_bad = int(nb.item())
     if rank != 0:
         return None
     bdim = 3 * n * n
@@ -649,7 +713,7 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
     if world == 1 and not args.no_cpu_baseline:
         avail = usable_cores()
         n_sample = max(1, min(8, avail, ntot))
-        rate, done, slowest = cpu_baseline_c5_multicore(args, n_sample)
+        rate, done, slowest = cpu_baseline_c5_multicore(args, n_sample, n)
         cpu = {
             "value": rate,
             "unit": "solves/s",
@@ -663,12 +727,13 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
         }
     rec = {
         "metric": "micro-cell solves/sec",
-        "value": ntot * args.steps / dt,
+        "value": ntot * steps / dt,
         "unit": "solves/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
+        "reserve_s": reserve_s,  # hommx_plan_reserve before the first step: the route's workspace (hipMalloc), outside the timed region
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -691,12 +756,13 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
             "unit": "TFLOP/s",
             "frac": achieved / FP64_PEAK_DATASHEET,
             "traffic": None,
-            "kernel": f"{plan.kernel} route of the blocked family (k_gemm_tile<...,128,8> dominant)",
+            "kernel": plan.route_detail,  # from the plan itself (hommx_plan_route_detail): route, tree, tile sizes
             "kernel_ms": kern_ms,
             "flops_per_solve": F_exec,
             "flop_model": "executed dense flops of the route by its own model (hommx_plan_flops_per_solve): nested dissection, sum over the "
-            "fronts of s^3 + 2 s^2 r + s r^2 on the padded front sizes; `frac` prices THESE (rounds 1-2 priced the plane elimination's "
-            "(6 (n-1) + 2) b^3, which this route no longer executes: flops_plane_model_per_solve / frac_plane_model for comparison)",
+            "fronts of the staged elimination + s r^2 on the PADDED front sizes -- `frac` therefore includes padding work and is not "
+            "comparable with rounds 1-2, which priced the plane elimination's (6 (n-1) + 2) b^3 (flops_plane_model_per_solve / "
+            "frac_plane_model); frac_ref prices the same time with F_ref and compares across rounds and routes",
             "flops_plane_model_per_solve": F,
             "frac_plane_model": F * nloc / (kern_ms * 1e-3) / FP64_PEAK_DATASHEET,
             "flops_ref_per_solve": fr["F_ref"],
@@ -709,11 +775,11 @@ def run_c5(args, torch, dist, use_dist, dev, rank, local_rank, world, MicroCellP
     # HBM traffic of the route: PMC counters need their own rocprofv3 passes, so the figure comes from the committed summary of
     # tools/profile_mf.sh (same problem size; FETCH_SIZE x 2 as the hardware guide prescribes on gfx950, + WRITE_SIZE), per solve
     try:
-        pm = json.load(open(os.path.join(HERE, "profiles", "r03_mf_pmc_summary.json")))
+        pm = json.load(open(os.path.join(HERE, MF_PMC_SUMMARY)))
         if plan.kernel == "multifrontal" and n == 16:
             rec["roofline"]["traffic"] = pm["hbm_bytes_per_cell_total"] * nloc
             rec["roofline"]["traffic_per_solve"] = pm["hbm_bytes_per_cell_total"]
-            rec["roofline"]["traffic_source"] = "profiles/r03_mf_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over all kernels of the route)"
+            rec["roofline"]["traffic_source"] = MF_PMC_SUMMARY + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over all kernels of the route)"
             rec["roofline"]["traffic_algorithmic_per_solve"] = 8.0 * (6 * n**3 * 2 + 9 + 36)  # coefficient stream + M + C_H
             rec["roofline"]["mfma_busy_fraction_gemm"] = pm["families"]["gemm_gather"]["mfma_busy_fraction_of_simd_cycles"]
             rec["roofline"]["hbm_GBps"] = pm["hbm_bytes_per_cell_total"] * nloc / (kern_ms * 1e-3) / 1e9

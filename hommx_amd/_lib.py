@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "hommx_plan_coef_components",
     "hommx_plan_tensor_size",
     "hommx_plan_kernel_name",
+    "hommx_plan_route_detail",
     "hommx_plan_flops_per_solve",
     "hommx_solve_batch",
     "hommx_solve_batch_device",
@@ -131,6 +132,8 @@ def load():
     lib.hommx_plan_flops_per_solve.argtypes = [vp]
     lib.hommx_plan_kernel_name.restype = C.c_char_p
     lib.hommx_plan_kernel_name.argtypes = [vp]
+    lib.hommx_plan_route_detail.restype = C.c_char_p
+    lib.hommx_plan_route_detail.argtypes = [vp]
     lib.hommx_solve_batch.restype = C.c_int
     lib.hommx_solve_batch.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.hommx_solve_batch_device.restype = C.c_int

@@ -40,6 +40,7 @@ class MicroCellPlan:
         self.n_comp = int(self._lib.hommx_plan_coef_components(h))
         self.t = int(self._lib.hommx_plan_tensor_size(h))
         self.kernel = self._lib.hommx_plan_kernel_name(h).decode()
+        self.route_detail = self._lib.hommx_plan_route_detail(h).decode()  # what that route launches for this plan (reports)
         self.flops_per_solve = float(self._lib.hommx_plan_flops_per_solve(h))  # dense flops of the route, by its own model
 
     def reserve(self, n_cells: int):

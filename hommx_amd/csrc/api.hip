@@ -194,6 +194,14 @@ const char* hommx_plan_kernel_name(const hommx_plan* p) {
   return p->family == FAM_FUSED2D ? "fused2d" : hommx::blocked_route_name(p->ws);
 }
 
+const char* hommx_plan_route_detail(hommx_plan* p) {
+  if (!p) return "";
+  if (p->family == FAM_FUSED2D)
+    return p->desc.n_micro > 16 ? "fused2d: k_poisson2d_fused<32>, one wavefront per macro cell, every matrix in the f64 MFMA accumulator layout"
+                                : "fused2d: k_poisson2d_fused<16>, one wavefront per macro cell, every matrix in the f64 MFMA accumulator layout";
+  return hommx::blocked_route_detail(p->ws);
+}
+
 int hommx_solve_batch_device(hommx_plan* p, int64_t n_cells, const double* d_coef, const double* d_M,
                              double* d_A_eff, int32_t* d_info, void* stream) {
   if (!p) return fail(HOMMX_EINVAL, "null plan");

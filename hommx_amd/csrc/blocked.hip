@@ -980,6 +980,26 @@ const char* blocked_route_name(const BlockedWorkspace* ws) {
   return "blocked";
 }
 
+// one line for reports (bench.py's roofline.kernel): what the route launches, derived from the plan itself
+const char* blocked_route_detail(BlockedWorkspace* ws) {
+  if (!ws) return "";
+  if (ws->detail.empty()) {
+    char buf[512];
+    const Geo& G = ws->G;
+    if (ws->mf) ws->detail = mf_describe(ws, ws->mf);
+    else if (G.b <= 64 && ws->small_fused) {
+      snprintf(buf, sizeof(buf), "%s: one launch after K1 (k_assemble_reg), plane block b = %d, f64 MFMA 16x16x4 tiles in %s", blocked_route_name(ws), G.b,
+               (G.b <= 48 && ws->small_waves != 2 && ws->small_waves != 4) ? "registers (one wavefront per macro cell)" : "LDS (several waves per macro cell)");
+      ws->detail = buf;
+    } else {
+      snprintf(buf, sizeof(buf), "blocked: plane elimination, b = %d (padded %d), k_gemm_tile %s f64-MFMA tiles, recursive block inverse on 32 / 64 leaves, strip-form sparse products",
+               G.b, G.Bp, G.Bp >= ws->gemm128_min ? "128x128 (8 waves) and 64x64 (4 waves)" : "64x64 (4 waves)");
+      ws->detail = buf;
+    }
+  }
+  return ws->detail.c_str();
+}
+
 double blocked_flops_per_cell(const BlockedWorkspace* ws) {
   if (!ws) return 0.0;
   if (ws->mf) return mf_flops_per_cell(ws->mf);
@@ -1270,12 +1290,41 @@ namespace {
 inline unsigned nblk(long long work, int bs = 256) { return (unsigned)((work + bs - 1) / bs); }
 }  // namespace
 
+// Super-block tile order of a lower triangle of `ty` tile rows (device table, cached per tile count).  The multifrontal route builds the
+// tables of all its groups when its workspace is reserved (mf_reserve), so that no allocation or blocking copy happens while streams are
+// being filled; a first use from anywhere else makes the table here.  A failed allocation falls back to the row-by-row order and leaves no
+// sticky HIP error behind.
+const int* ensure_tilemap(BlockedWorkspace* ws, int ty) {
+  auto it = ws->tilemaps.find(ty);
+  if (it != ws->tilemaps.end()) return it->second;
+  const int SB = ws->tile_sb;
+  std::vector<int> order;
+  order.reserve((size_t)ty * (ty + 1) / 2);
+  for (int I = 0; I < ty; I += SB)
+    for (int J = 0; J <= I; J += SB)
+      for (int i = I; i < std::min(I + SB, ty); ++i)
+        for (int j = J; j < std::min(J + SB, ty) && j <= i; ++j) order.push_back(i << 16 | j);
+  int* d = nullptr;
+  if (hipMalloc(&d, sizeof(int) * order.size()) == hipSuccess &&
+      hipMemcpy(d, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice) == hipSuccess)
+    return ws->tilemaps.emplace(ty, d).first->second;
+  if (d) (void)hipFree(d);
+  (void)hipGetLastError();  // the fallback is legitimate: do not let the failure surface later as somebody else's error
+  return nullptr;
+}
+
+// tile size gemm() picks for an M x N (x K) product of this workspace
+static inline bool gemm_big(const BlockedWorkspace* ws, int M, int N, int K, bool gather) {
+  return M >= ws->gemm128_min && N >= ws->gemm128_min && !(gather && K < ws->mf_gather128_min_k);
+}
+int gemm_tile_size(const BlockedWorkspace* ws, int M, int N, int K, bool gather) { return gemm_big(ws, M, N, K, gather) ? 128 : 64; }
+
 void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, const double* A, int lda, long long sA,
           const double* B, int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly, double* Ct,
           const GatherC* gather) {
-  const int min128 = c.ws->gemm128_min;  // dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles)
-  // a gathering update of small rank is bound by the traffic of the tiles it touches: 64-tiles waste less of the lower triangle
-  const bool big = M >= min128 && N >= min128 && !(gather && K < c.ws->mf_gather128_min_k);
+  // gemm128_min is a dev knob: smallest M, N routed to the 128x128 tiles (tests lower it to cover partial tiles); a gathering update of
+  // small rank is bound by the traffic of the tiles it touches: 64-tiles waste less of the lower triangle
+  const bool big = gemm_big(c.ws, M, N, K, gather != nullptr);
   const int TM = big ? 128 : 64;
   const int tx = (N + TM - 1) / TM, ty = (M + TM - 1) / TM;
   const int T = lowerOnly ? ty * (ty + 1) / 2 : tx * ty;
@@ -1300,25 +1349,7 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
   }
   // Big lower-triangle updates walk their tiles in SB x SB super-blocks: row by row a tile row of a 1,536-front touches 8 MB of B panels,
   // twice an XCD's L2, and every panel is fetched once per tile (the rank-672 update of C4 fetched 143 MB per cell for 52 MB of operands)
-  const int* tilemap = nullptr;
-  if (lowerOnly && c.ws->tile_sb > 1 && ty >= 2 * c.ws->tile_sb) {
-    auto it = c.ws->tilemaps.find(ty);
-    if (it == c.ws->tilemaps.end()) {
-      const int SB = c.ws->tile_sb;
-      std::vector<int> order;
-      order.reserve(T);
-      for (int I = 0; I < ty; I += SB)
-        for (int J = 0; J <= I; J += SB)
-          for (int i = I; i < std::min(I + SB, ty); ++i)
-            for (int j = J; j < std::min(J + SB, ty) && j <= i; ++j) order.push_back(i << 16 | j);
-      int* d = nullptr;
-      if (hipMalloc(&d, sizeof(int) * order.size()) == hipSuccess &&
-          hipMemcpy(d, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice) == hipSuccess)
-        it = c.ws->tilemaps.emplace(ty, d).first;
-      else if (d) (void)hipFree(d);
-    }
-    if (it != c.ws->tilemaps.end()) tilemap = it->second;
-  }
+  const int* tilemap = (lowerOnly && c.ws->tile_sb > 1 && ty >= 2 * c.ws->tile_sb) ? ensure_tilemap(c.ws, ty) : nullptr;
   dim3 grid((unsigned)(groups * 8 * T));
   // 128 tiles: 8 waves per workgroup (2 x 4 grid of 64 x 32 wave tiles, 110 VGPRs, 4 waves per SIMD): +2 % over 4 waves
   // of 64 x 64; 64 tiles: 4 waves of 32 x 32 (8 waves measured slower)

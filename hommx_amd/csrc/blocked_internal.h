@@ -42,6 +42,7 @@ struct BlockedWorkspace {
   // tile orders of big lower-triangle updates (gemm): device tables, one per tile count, made on first use
   int tile_sb = 4;                // HOMMX_TILE_SB: tiles walk the lower triangle in SB x SB super-blocks (0: row by row)
   std::map<int, int*> tilemaps;
+  std::string detail;             // hommx_plan_route_detail: written once, on first request
 };
 
 
@@ -83,6 +84,11 @@ void gemm(const Ctx& c, bool ta, bool tb, int M, int N, int K, double alpha, con
           int ldb, long long sB, double beta, double* C, int ldc, long long sC, int lowerOnly = 0, double* Ct = nullptr,
           const GatherC* gather = nullptr);
 
+// tile edge (64 or 128) gemm() uses for an M x N x K product of this workspace, and the super-block tile order of a lower triangle of `ty`
+// tile rows (device table cached in the workspace; nullptr: row-by-row order)
+int gemm_tile_size(const BlockedWorkspace* ws, int M, int N, int K, bool gather);
+const int* ensure_tilemap(BlockedWorkspace* ws, int ty);
+
 // in-place inverse of the SPD diagonal block [off, off + size) of every matrix of the batch (recursive Schur-complement form;
 // size a multiple of 32); `tmp`: scratch of at least size^2 / 2 doubles per matrix, batch stride c.sT
 void invert(const Ctx& c, double* S, int off, int size, double* tmp);
@@ -93,6 +99,7 @@ extern thread_local std::string g_berr;
 int mf_plan_create(MfPlan** out, const Geo& G, bool keep = false);
 void mf_plan_destroy(MfPlan* p);
 double mf_flops_per_cell(const MfPlan* p);
+std::string mf_describe(const BlockedWorkspace* ws, const MfPlan* p);  // one line: tree, stages, streams, tile sizes of the dense kernels
 int mf_reserve(BlockedWorkspace* ws, MfPlan* P, long long ncells, bool ahead);
 // effective tensors, and with the corrector plan (keep = true) and d_corr != nullptr the correctors [cell][t][n^d bs] as well
 int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_coef, const double* d_M, double* d_out, int32_t* d_info,

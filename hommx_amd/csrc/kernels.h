@@ -63,6 +63,7 @@ const char* blocked_last_error();
 int blocked_reserve(BlockedWorkspace* ws, long long n_cells);
 // "small_wave" (b <= 48), "small_fused" (48 < b <= 64) or "blocked": the route blocked_solve takes for effective tensors
 const char* blocked_route_name(const BlockedWorkspace* ws);
+const char* blocked_route_detail(BlockedWorkspace* ws);
 // dense flops one micro-cell solve executes on this route, by the route's own model (multifrontal: sum over the fronts of
 // s^3 + 2 s^2 r + s r^2 on the padded sizes; plane elimination: (6 (n - 1) + 2) b^3)
 double blocked_flops_per_cell(const BlockedWorkspace* ws);

@@ -88,7 +88,9 @@ struct hommx_comm {
   // scratch of hommx_solve_batch_multi, per device (grown on demand)
   std::vector<double*> d_coef, d_M, d_field, d_packed;
   std::vector<int32_t*> d_info;
-  std::vector<int64_t> cap_cells, cap_field, cap_info;
+  // capacities in ELEMENTS of each buffer (doubles / int32): a communicator reused with plans of another kind or n_micro must regrow
+  // them even when the cell count per device stays the same
+  std::vector<int64_t> cap_coef, cap_M, cap_packed, cap_field, cap_info;
 };
 
 extern "C" {
@@ -146,7 +148,9 @@ int hommx_comm_init_all(hommx_comm** out, int ndev, const int* devs) {
   c->d_field.assign(ndev, nullptr);
   c->d_packed.assign(ndev, nullptr);
   c->d_info.assign(ndev, nullptr);
-  c->cap_cells.assign(ndev, 0);
+  c->cap_coef.assign(ndev, 0);
+  c->cap_M.assign(ndev, 0);
+  c->cap_packed.assign(ndev, 0);
   c->cap_field.assign(ndev, 0);
   c->cap_info.assign(ndev, 0);
   for (int i = 0; i < ndev; ++i)
@@ -243,16 +247,18 @@ void drain(hommx_comm* c, int upto) {
   }
 }
 
-int ensure_field(hommx_comm* c, int i, int64_t need) {
-  if (need > c->cap_field[i]) {
-    if (c->d_field[i]) hipFree(c->d_field[i]);
-    c->d_field[i] = nullptr;
-    c->cap_field[i] = 0;
-    HIP_TRY(hipMalloc(&c->d_field[i], sizeof(double) * need));
-    c->cap_field[i] = need;
+// grow one per-device scratch buffer to `need` doubles (capacity tracked per buffer, in doubles)
+int ensure(double** buf, int64_t* cap, int64_t need) {
+  if (need > *cap) {
+    if (*buf) hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(buf, sizeof(double) * need));
+    *cap = need;
   }
   return HOMMX_OK;
 }
+int ensure_field(hommx_comm* c, int i, int64_t need) { return ensure(&c->d_field[i], &c->cap_field[i], need); }
 }  // namespace
 
 int hommx_solve_batch_multi_device(hommx_comm* c, hommx_plan* const* plans, int64_t n_cells, const double* const* d_coef_per_dev,
@@ -326,19 +332,10 @@ int hommx_solve_batch_multi(hommx_comm* c, hommx_plan* const* plans, int64_t n_c
     int rc = HOMMX_OK;
     do {
       if (hipSetDevice(c->devs[i]) != hipSuccess) { rc = fail(HOMMX_EHIP, "hipSetDevice(%d) failed", c->devs[i]); break; }
-      if (per > c->cap_cells[i]) {
-        if (c->d_coef[i]) hipFree(c->d_coef[i]);
-        if (c->d_M[i]) hipFree(c->d_M[i]);
-        if (c->d_packed[i]) hipFree(c->d_packed[i]);
-        c->d_coef[i] = c->d_M[i] = c->d_packed[i] = nullptr;
-        c->cap_cells[i] = 0;
-        if (hipMalloc(&c->d_coef[i], sizeof(double) * per * per_coef) != hipSuccess || hipMalloc(&c->d_M[i], sizeof(double) * per * d * d) != hipSuccess ||
-            hipMalloc(&c->d_packed[i], sizeof(double) * P * per * row) != hipSuccess) {
-          rc = fail(HOMMX_ENOMEM, "staging buffers on device %d", c->devs[i]);
-          break;
-        }
-        c->cap_cells[i] = per;
-      }
+      // sizes depend on the plans (per_coef, d, row), not only on the cells per device: one capacity per buffer
+      if ((rc = ensure(&c->d_coef[i], &c->cap_coef[i], per * per_coef)) != HOMMX_OK || (rc = ensure(&c->d_M[i], &c->cap_M[i], per * d * d)) != HOMMX_OK ||
+          (rc = ensure(&c->d_packed[i], &c->cap_packed[i], (int64_t)P * per * row)) != HOMMX_OK)
+        break;
       if (nloc > 0) {
         if (hipMemcpyAsync(c->d_coef[i], coef + b * per_coef, sizeof(double) * nloc * per_coef, hipMemcpyHostToDevice, c->streams[i]) != hipSuccess ||
             (M && hipMemcpyAsync(c->d_M[i], M + b * d * d, sizeof(double) * nloc * d * d, hipMemcpyHostToDevice, c->streams[i]) != hipSuccess)) {

@@ -204,6 +204,22 @@ int upload(T** dst, const std::vector<T>& src) {
 
 double mf_flops_per_cell(const MfPlan* p) { return p ? p->flops_per_cell : 0.0; }
 
+std::string mf_describe(const BlockedWorkspace* ws, const MfPlan* p) {
+  if (!p) return "";
+  bool t64 = false, t128 = false;
+  for (const MfGroup& mg : p->groups) (gemm_tile_size(ws, mg.rp, mg.rp, mg.sp, true) == 128 ? t128 : t64) = true;
+  const MfGroup& top = p->groups.back();
+  const MfGroup& leaf = p->groups.front();
+  char buf[640];
+  snprintf(buf, sizeof(buf),
+           "multifrontal: nested dissection, %d fronts in %d groups (leaves s = %d, r = %d x %d; root s = %d), stages of %d unknowns, up to %d stream(s) per "
+           "chunk; batched launches per group: k_mf_build, recursive block inverse (k_leaf_inverse / k_leaf_inverse_blk<64> + k_gemm_tile), X = N E^T and "
+           "column updates on k_gemm_tile<%s>, gathering Schur update k_gemm_tile<%s%s, GATHER> (the dominant kernel)",
+           p->nfronts, (int)p->groups.size(), leaf.ns * ws->G.bs, leaf.rb, leaf.nf, top.ns * ws->G.bs, p->stage, std::max(1, std::min(4, p->streams)),
+           ws->gemm128_min < (1 << 29) ? "64x64 / 128x128" : "64x64, 4 waves", t64 ? "64x64, 4 waves" : "", t128 ? (t64 ? " / 128x128, 8 waves" : "128x128, 8 waves") : "");
+  return buf;
+}
+
 void mf_plan_destroy(MfPlan* p) {
   if (!p) return;
   for (MfGroup& g : p->groups) {
@@ -707,6 +723,13 @@ int mf_reserve(BlockedWorkspace* ws, MfPlan* P, long long ncells, bool ahead) {
   if (chunk < 1) chunk = 1;
   if (chunk > 4096) chunk = 4096;
   if (chunk > ncells) chunk = ncells;
+  // tile orders of the gathering Schur updates of every group, made here: no allocation and no blocking copy later, while the streams fill
+  if (ws->tile_sb > 1)
+    for (const MfGroup& mg : P->groups)
+      for (int mn : {mg.rb, mg.rp}) {
+        const int TM = gemm_tile_size(ws, mn, mn, mg.sp, true), ty = (mn + TM - 1) / TM;
+        if (mn > 0 && ty >= 2 * ws->tile_sb) (void)ensure_tilemap(ws, ty);
+      }
   if (chunk <= P->chunk) return 0;
   for (double** p : {&P->arena, &P->scratch, &P->vbuf, &P->Kst, &P->Brhs, &P->C0}) {
     if (*p) (void)hipFree(*p);
@@ -873,13 +896,24 @@ int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_
   // the batch it is in: results are bitwise the same.
   const int want = std::max(1, std::min(4, P->streams));
   const bool two = want >= 2 && step_cells >= 16;
-  if (two && !P->ev_fork) {
+  if (two) {  // every stream / event only if its own slot is still empty: a call that failed part-way leaks nothing on the next one
     for (int k = 0; k + 1 < want; ++k) {
-      MTRY(hipStreamCreateWithFlags(&P->side[k], hipStreamNonBlocking));
-      MTRY(hipEventCreateWithFlags(&P->ev_join[k], hipEventDisableTiming));
+      if (!P->side[k]) MTRY(hipStreamCreateWithFlags(&P->side[k], hipStreamNonBlocking));
+      if (!P->ev_join[k]) MTRY(hipEventCreateWithFlags(&P->ev_join[k], hipEventDisableTiming));
     }
-    MTRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+    if (!P->ev_fork) MTRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
   }
+  // an error after the fork must not leave work on the plan-owned streams that the caller's stream never waits for
+  int forked = 0;
+#define MTRY_J(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      g_berr = std::string(#expr) + ": " + hipGetErrorString(e__);                        \
+      for (int k__ = 1; k__ < forked; ++k__) (void)hipStreamSynchronize(P->side[k__ - 1]); \
+      return e__ == hipErrorOutOfMemory ? HOMMX_ENOMEM : HOMMX_EHIP;                      \
+    }                                                                                     \
+  } while (0)
   const int bs = G.bs;
   for (long long c0 = 0; c0 < ncells; c0 += step_cells) {
     const long long nc = std::min(step_cells, ncells - c0);
@@ -894,7 +928,10 @@ int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_
         halves[k] = MfHalf{c0 + a, b - a, a, k == 0 ? st : P->side[k - 1]};
       }
       MTRY(hipEventRecord(P->ev_fork, st));  // the side streams start behind everything queued on st (inputs, the previous chunk)
-      for (int k = 1; k < nh; ++k) MTRY(hipStreamWaitEvent(P->side[k - 1], P->ev_fork, 0));
+      for (int k = 1; k < nh; ++k) {
+        forked = k + 1;
+        MTRY_J(hipStreamWaitEvent(P->side[k - 1], P->ev_fork, 0));
+      }
     }
     for (int k = 0; k < nh; ++k) {
       const MfHalf& h = halves[k];
@@ -919,11 +956,13 @@ int mf_solve(BlockedWorkspace* ws, MfPlan* P, long long ncells, const double* d_
         launch_center_corr(ws, d_corr + halves[k].c0 * G.t * (long long)G.nn * bs, halves[k].nc, halves[k].st);
     }
     for (int k = 1; k < nh; ++k) {  // st continues (next chunk, the caller's work) when every piece is done
-      MTRY(hipEventRecord(P->ev_join[k - 1], P->side[k - 1]));
-      MTRY(hipStreamWaitEvent(st, P->ev_join[k - 1], 0));
+      MTRY_J(hipEventRecord(P->ev_join[k - 1], P->side[k - 1]));
+      MTRY_J(hipStreamWaitEvent(st, P->ev_join[k - 1], 0));
     }
-    MTRY(hipGetLastError());
+    MTRY_J(hipGetLastError());
+    forked = 0;
   }
+#undef MTRY_J
   return 0;
 }
 

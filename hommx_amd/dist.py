@@ -26,14 +26,53 @@ def shard_range(n_cells: int, rank: int, world: int) -> tuple[int, int, int]:
     return b, e, per
 
 
+_selected_device: int | None = None  # the caller's explicit choice (select_device); honoured even when it is ordinal 0
+
+
+def select_device(device: int | None) -> None:
+    """Record the device this rank's plans shall use (and make it torch's current device when torch is loaded and sees a GPU).
+    ``torch.cuda.set_device(0)`` alone cannot be told from the untouched default, so a caller that MEANS ordinal 0 under a launcher
+    whose LOCAL_RANK says otherwise calls this (or passes ``device=0`` to the solver class).  ``None`` forgets the choice."""
+    import sys
+
+    global _selected_device
+    _selected_device = None if device is None else int(device)
+    torch = sys.modules.get("torch")
+    if device is not None and torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(int(device))
+
+
+def _group_bound_device():
+    """Device a process group was bound to with ``init_process_group(..., device_id=...)``: an explicit choice as well."""
+    import sys
+
+    dist = sys.modules.get("torch.distributed")
+    try:
+        if dist is None or not (dist.is_available() and dist.is_initialized()):
+            return None
+        pg = dist.distributed_c10d._get_default_group()
+        dev = getattr(pg, "bound_device_id", None)
+        if dev is not None and dev.type == "cuda" and dev.index is not None:
+            return int(dev.index)
+    except Exception:
+        pass
+    return None
+
+
 def default_device(device_count=None) -> int:
-    """Device ordinal a rank should use when the caller did not choose one.  Resolved LAZILY, at the first solve (a solver may be
-    built before ``init_process_group`` / ``torch.cuda.set_device``):  the torch device the caller has already selected
-    (``torch.cuda.current_device()`` when it is not the untouched default 0), else ``LOCAL_RANK % visible devices`` (a launcher
-    that exposes one device per rank through HIP_VISIBLE_DEVICES leaves exactly one visible ordinal, 0), else 0."""
+    """Device ordinal a rank should use when no ``device=`` was passed.  Resolved LAZILY, at the first solve (a solver may be built
+    before ``init_process_group`` / ``torch.cuda.set_device``).  In this order: the ordinal recorded by ``select_device`` (0
+    included); the device the default process group is bound to (``device_id=``); the torch device the caller has already selected
+    when it is not the untouched default 0; ``LOCAL_RANK % visible devices`` (a launcher that exposes one device per rank through
+    HIP_VISIBLE_DEVICES leaves exactly one visible ordinal, 0); else 0."""
     import os
     import sys
 
+    if _selected_device is not None:
+        return _selected_device
+    bound = _group_bound_device()
+    if bound is not None:
+        return bound
     torch = sys.modules.get("torch")
     if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
         cur = int(torch.cuda.current_device())

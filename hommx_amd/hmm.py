@@ -213,6 +213,7 @@ class BaseHMM(ABC):
         quadrature_degree: int | None = None,
         rhs_quadrature_degree: int = 6,
         device: int | None = None,
+        reserve: bool = False,
     ):
         """``quadrature_degree``: degree of the micro quadrature rule that samples ``A(x, .)``.  The reference lets UFL estimate it
         from the expression (hmm.py:190-198 + fem.form at :644-647): 0 for a ``conditional`` between constants, 3 for one
@@ -223,8 +224,13 @@ class BaseHMM(ABC):
         element, or only a handful of distinct values over the cell -> centroid rule (degree 0), anything else -> degree 3 --
         logs the choice with its evidence at WARNING level and raises when the three cells disagree.  Pass an integer to choose
         the rule yourself; ``TwoPhase`` / ``Separable`` coefficients carry their own degree and never guess.
-        ``device``: HIP device ordinal; resolved at the first solve (``dist.default_device``: the torch device the caller selected,
-        else LOCAL_RANK modulo the visible devices, else 0)."""
+        ``device``: HIP device ordinal; resolved at the first solve (``dist.default_device``: the ordinal given to
+        ``dist.select_device``, the process group's bound device, the torch device the caller selected, else LOCAL_RANK modulo the
+        visible devices, else 0).
+        ``reserve``: create the plan and allocate its device workspace for this rank's share of the macro cells NOW (``prepare()``)
+        instead of inside the first ``solve()`` -- the nested-dissection route of the C4 / C5 size holds 0.2 GB of fronts per cell
+        of a chunk, 0.5 - 3 s of ``hipMalloc`` that the first assembly would otherwise hide.  Resolves the device at construction
+        time, so leave it off when the solver is built before ``init_process_group``; ``prepare()`` can be called later."""
         self._logger = logging.getLogger(__name__)
         self._msh = msh
         self._comm = msh.comm
@@ -254,6 +260,7 @@ class BaseHMM(ABC):
             self.quadrature_degree_used = A.degree
         self._rhs_degree = rhs_quadrature_degree
         self._device = device  # None: resolved lazily in _ensure_plan (the solver may be built before init_process_group)
+        self._reserve_at_construction = bool(reserve)
 
         self._V_macro = self._setup_macro_function_space()
         self._macro_coordinates = self._V_macro.tabulate_dof_coordinates()
@@ -273,6 +280,8 @@ class BaseHMM(ABC):
         self._plan: MicroCellPlan | None = None
         self.effective_tensors: np.ndarray | None = None  # A_H / C_H of every macro cell after assembly
         self.cell_info: np.ndarray | None = None
+        if self._reserve_at_construction:
+            self.prepare()
 
     # -- API ---------------------------------------------------------------------------------------
     @property
@@ -441,7 +450,12 @@ class BaseHMM(ABC):
         if nc == 0:
             return np.empty((0, d, d))
         first, last = one(c[0]), one(c[-1])
+        known = {0: first, nc - 1: last}
         if nc >= 4:
+            # the broadcast result is accepted only if it reproduces the per-cell call (what the reference does, hmm.py:756-757) on the
+            # first, the middle, the last and a few more cells spread over the batch -- a callable that broadcasts but reduces over its
+            # argument, or indexes into it, agrees at the ends at best
+            probe = sorted({nc // 2, nc // 3, (2 * nc) // 3, (7 * nc) // 11, 1, nc - 2} - {0, nc - 1})
             try:
                 rows = self._Dtheta_t(c.T)
                 mb = np.empty((d, d, nc))
@@ -449,14 +463,16 @@ class BaseHMM(ABC):
                     for j in range(d):
                         mb[i, j] = np.broadcast_to(np.asarray(rows[i][j], dtype=float), (nc,))
                 mb = np.ascontiguousarray(np.moveaxis(mb, -1, 0))
-                if np.array_equal(mb[0], first) and np.array_equal(mb[-1], last):
+                for k in probe:
+                    known[k] = one(c[k])
+                if all(np.array_equal(mb[k], v) for k, v in known.items()):
                     return mb
-            except Exception:
-                pass
+                self._logger.debug("Dtheta_transpose: the broadcast call disagrees with the per-cell calls; evaluating cell by cell")
+            except Exception as exc:
+                self._logger.debug(f"Dtheta_transpose: no broadcast evaluation ({type(exc).__name__}: {exc}); evaluating cell by cell")
         M = np.empty((nc, d, d))
-        M[0], M[-1] = first, last
-        for k in range(1, nc - 1):
-            M[k] = one(c[k])
+        for k in range(nc):
+            M[k] = known[k] if k in known else one(c[k])
         return M
 
     # -- the hot path (replaces the loop hmm.py:298-332) ---------------------------------------------
@@ -468,14 +484,48 @@ class BaseHMM(ABC):
         dist = sys.modules.get("torch.distributed")
         return dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def _ensure_plan(self, kind: str) -> MicroCellPlan:
+    def _ensure_plan(self, kind: str, n_cells: int | None = None) -> MicroCellPlan:
+        """The plan of this solver (created on first use: replaces the per-solve object construction of hmm.py:420-425).  With
+        ``n_cells`` (``prepare()`` / ``reserve=True``) the plan's device workspace is allocated for batches of that size right away
+        (``hommx_plan_reserve``); a solve without it allocates what its first batch needs (half as much on the C4 / C5 route: a caller
+        who pays ahead of many batches gets the bigger chunks, one who pays inside the only solve does not want to)."""
         if self._plan is None or self._plan.kind != kind:
             if self._device is None:
                 from .dist import default_device
 
                 self._device = default_device()
             self._plan = MicroCellPlan(self._tdim, self._n_micro, kind, device=self._device)
+            self._reserved_cells = 0
+        if n_cells and n_cells > getattr(self, "_reserved_cells", 0) and hasattr(self._plan, "reserve"):
+            self._plan.reserve(int(n_cells))
+            self._reserved_cells = int(n_cells)
         return self._plan
+
+    def _local_cell_count(self) -> int:
+        """Macro cells this rank solves: all of them, or its block under a process group (hmm.py:307-310)."""
+        n = self._msh.num_cells
+        if self._sharded():
+            import torch.distributed as dist
+
+            from .dist import shard_range
+
+            b, e, _ = shard_range(n, dist.get_rank(), dist.get_world_size())
+            return e - b
+        return n
+
+    def prepare(self) -> "BaseHMM":
+        """Create the plan and allocate its device workspace for this rank's share of the macro cells now, so that the first
+        ``solve()`` does not pay for it (not in the reference's API: there every PETSc object is made per solve, hmm.py:420-425).
+        The kernel family depends on the coefficient's shape, which a plain callable only shows when sampled: one macro cell is
+        sampled for that."""
+        if isinstance(self._coeff, (TwoPhase, Separable)):
+            kind = "poisson" if self._kind == "poisson" else "elasticity"
+            if isinstance(self._coeff, Separable) and self._kind != "poisson" and self._coeff.family != "affine":
+                kind = self._element_means(np.array([0]))[1]
+        else:
+            kind = self._element_means(np.array([0]))[1]
+        self._ensure_plan(kind, self._local_cell_count())
+        return self
 
     def _shard_device(self):
         """Device of the gather buffer under RCCL = the plan's device (None before a plan exists on a gloo / stub-plan run)."""

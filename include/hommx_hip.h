@@ -94,7 +94,7 @@ int hommx_plan_reserve(hommx_plan* plan, int64_t n_cells);
  * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), the descriptor fields, and the name of the
  * kernel route the plan's effective-tensor solves take: "fused2d" (2D scalar Poisson, n <= 32), "small_wave" (plane block
  * b <= 48: one wavefront per cell), "small_fused" (48 < b <= 64: LDS), "multifrontal" (large plane blocks, e.g. 3D elasticity
- * from 5^3 micro cells: nested dissection, batched fronts) or "blocked" (everything else, and the corrector entry point of every plan). */
+ * from 5^3 micro cells: nested dissection, batched fronts) or "blocked" (everything else: plane elimination; also the corrector entry point of plans whose tensors take a one-launch route). */
 int32_t hommx_plan_dim(const hommx_plan* plan);
 int32_t hommx_plan_device(const hommx_plan* plan);
 int32_t hommx_plan_n_micro(const hommx_plan* plan);
@@ -103,6 +103,9 @@ int64_t hommx_plan_num_elements(const hommx_plan* plan);
 int32_t hommx_plan_coef_components(const hommx_plan* plan);
 int32_t hommx_plan_tensor_size(const hommx_plan* plan);
 const char* hommx_plan_kernel_name(const hommx_plan* plan);
+/* One line describing what that route launches for THIS plan (kernel names with their tile sizes, tree shape of the nested dissection,
+ * stage size, streams): for reports -- bench.py's roofline.kernel label is this string, so it cannot drift from the code. */
+const char* hommx_plan_route_detail(hommx_plan* plan);
 /* Dense flops ONE micro-cell solve executes on the plan's route, by the route's own model: block-cyclic plane
  * elimination (6 (n-1) + 2) b^3; multifrontal: sum over the fronts of s^3 + 2 s^2 r + s r^2 on the padded front sizes. */
 double hommx_plan_flops_per_solve(const hommx_plan* plan);
@@ -182,7 +185,9 @@ int hommx_solve_batch_separable_device(hommx_plan* plan, int64_t n_cells, int32_
  * These are the functions the reference keeps in self._correctors (hmm.py:204-207, 431) / PoissonPeriodicHMM.correctors
  * (hmm.py:1211-1213, 1239-1240), for the canonical loads instead of the nb macro basis functions: the corrector of a
  * macro basis function is the linear combination  eps * sum_m (grad phi_i)_m chi_m  (SURVEY A.2, row A5).
- * Runs on the blocked kernel family for every plan (the fused 2D kernel never forms the factors). */
+ * Route: plans whose tensors take the nested-dissection route get the correctors by back substitution down the same elimination tree
+ * (a second plan of that tree whose fronts all stay resident; HOMMX_MF_CORR=0: plane elimination); every other plan runs the plane
+ * elimination of the blocked family here (the one-launch kernels and the fused 2D kernel never form the factors). */
 int hommx_solve_batch_correctors(hommx_plan* plan, int64_t n_cells, const double* coef, const double* M,
                                  double* A_eff, double* correctors, int32_t* info);
 

@@ -76,3 +76,21 @@ def test_under_a_launcher_runs_inline():
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["ranks_seen_in_gathered_field"] == [1]
+
+
+def test_eight_ranks_ragged_c5_shape():
+    """eight gloo ranks on a ragged C5 shape (6 * 3 * 1 * 1 = 18 cells, 18 % 8 != 0: shards of 3 cells, the last two
+    ranks own 0 cells) with the stub plan: the line says n_gpus == 8, every cell of the field was written exactly once by the rank
+    that owns it, empty ranks took part in the collective, and the all-gather time is reported."""
+    r = _run(["--gpus", "8", "--config", "C5", "--dry-run-cpu", "--dry-run-devices", "8", "--steps", "1", "--warmup", "0",
+              "--c5-shape", "3", "1", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["dry_run"] is True and rec["value"] is None and rec["scaling"] == "strong"
+    assert rec["config"]["cells_total"] == 18
+    assert rec["cells_per_rank"] == [3, 3, 3, 3, 3, 3, 0, 0]
+    assert rec["owner_of_cell"] == [1 + c // 3 for c in range(18)]   # every shard present once, in order, no padding leaked
+    assert rec["ranks_seen_in_gathered_field"] == [1, 2, 3, 4, 5, 6]
+    assert rec["allgather_ms"] is not None and rec["allgather_ms"] >= 0.0

@@ -50,14 +50,17 @@ def _worker(rank, world, port, n_cells, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_allgather():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,n_cells", [(2, 7), (8, 19)])  # ragged on purpose: 8 ranks x 3 cells, rank 6 owns one cell, rank 7 none
+def test_two_rank_shard_and_allgather(world, n_cells):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    n_cells = 7  # odd on purpose: ragged shards, one padded
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_cells, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_cells, q)) for r in range(world)]
     for p in procs:
         p.start()
     full, full2 = q.get(timeout=180)
@@ -234,3 +237,22 @@ def test_default_device_is_resolved_lazily(monkeypatch):
     assert h._device is None                      # nothing decided at construction time
     h2 = hmm.PoissonHMM(mesh.create_unit_square(2, 2), lambda x, y: 1.0 + 0 * y[0], lambda x: 1.0, mesh.create_unit_square(4, 4), 0.1, device=5)
     assert h2._device == 5                        # an explicit device always wins
+
+
+def test_explicit_device_zero_is_honoured(monkeypatch):
+    """`current_device() == 0` used to read as "not chosen", so an explicit choice of ordinal 0 under
+    LOCAL_RANK=3 was overridden.  The caller's choice is now tracked (dist.select_device), 0 included."""
+    sys.path.insert(0, ROOT)
+    from hommx_amd import dist as D
+
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    try:
+        assert D.default_device(device_count=8) == 3
+        D.select_device(0)
+        assert D.default_device(device_count=8) == 0
+        D.select_device(5)
+        assert D.default_device(device_count=8) == 5
+        D.select_device(None)
+        assert D.default_device(device_count=8) == 3
+    finally:
+        D.select_device(None)

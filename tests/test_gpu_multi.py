@@ -67,6 +67,18 @@ def test_solve_batch_multi_one_device():
         assert np.array_equal(info, ref_info) and info[4] > 0
         ok = info == 0
         assert np.array_equal(A[ok], ref[ok])
+        # ONE communicator reused with plans of another kind / dimension at the SAME cell count: the staging buffers are sized from
+        # the plans (coefficients per cell, d x d, t*t + 1 per row), not only from the cells per device (advisor, round 3)
+        for kind, dim, n in (("poisson", 2, 16), ("elasticity", 3, 3), ("poisson", 2, 8), ("elasticity", 3, 4)):
+            pk = MicroCellPlan(dim, n, kind)
+            shape = (23, pk.n_el) + ((pk.n_comp,) if pk.n_comp > 1 else ())
+            coef = rng.uniform(0.3, 3.0, size=shape)
+            M = np.eye(dim)[None] + 0.2 * rng.standard_normal((23, dim, dim))
+            ref = pk.solve(coef, M)
+            A = np.empty((23, pk.t, pk.t)); info = np.empty(23, np.int32)
+            plans = (ctypes.c_void_p * 1)(pk._h.value)
+            _lib.check(lib.hommx_solve_batch_multi(h, plans, 23, coef.ctypes.data, M.ctypes.data, A.ctypes.data, info.ctypes.data), "multi reuse")
+            assert np.array_equal(A, ref) and not info.any(), (kind, dim, n)
         assert lib.hommx_comm_init_all(ctypes.byref(ctypes.c_void_p()), 2, (ctypes.c_int * 2)(0, 0)) == -1  # the same device twice
         lib.hommx_comm_destroy(h)
         print("ok")

@@ -230,3 +230,59 @@ def test_separable_host_stream_and_asymmetric_matrix_coefficient():
     Asym = lambda x, y: np.broadcast_to(np.array([[2.0, 0.3], [0.3, 1.0]]), (y.shape[1], 2, 2))
     coef, kind = hmm.PoissonHMM(msh, Asym, lambda x: 1.0, mic, 0.01)._element_means(np.arange(msh.num_cells))
     assert kind == "poisson_matrix" and coef.shape == (8, 72, 3)
+
+
+def test_stratification_rejects_a_broadcast_that_is_wrong_in_the_interior(caplog):
+    """a Dtheta_transpose that happens to broadcast but is wrong for interior cells (here: it reduces over its
+    argument when handed the whole batch, yet the first and the last cell coincide with the per-cell call) must not be
+    accepted on the evidence of the two end cells; the reference only ever calls it per cell (hmm.py:756-757)."""
+    import logging
+
+    msh = mesh.create_unit_square(4, 4)
+
+    def dtheta(x):  # batch call: every cell gets the value of the batch's first cell in the (0, 1) entry, except the last one
+        x = np.asarray(x, dtype=float)
+        if x.ndim == 1:
+            return np.array([[1.0, np.cos(x[0])], [0.0, 1.0]])
+        off = np.full(x.shape[1], np.cos(x[0, 0]))
+        off[-1] = np.cos(x[0, -1])
+        return [[np.ones(x.shape[1]), off], [np.zeros(x.shape[1]), np.ones(x.shape[1])]]
+
+    h = hmm.PoissonStratifiedHMM(msh, lambda x, y: 1.0 + 0 * y[0], lambda x: 1.0, mesh.create_unit_square(4, 4), 0.1, dtheta)
+    cells = np.arange(msh.num_cells)
+    with caplog.at_level(logging.DEBUG, logger="hommx_amd.hmm"):
+        M = h._stratification(cells)
+    c = msh.cell_midpoints()[cells]
+    assert np.array_equal(M[:, 0, 1], np.cos(c[:, 0]))  # per-cell values everywhere
+    assert any("broadcast call disagrees" in r.message for r in caplog.records)
+    # a correct vectorised callable still takes the one-call path, bit for bit
+    good = lambda x: [[1.0 + 0 * x[0], np.cos(x[0])], [0 * x[0], 1.0 + 0 * x[0]]]
+    h2 = hmm.PoissonStratifiedHMM(msh, lambda x, y: 1.0 + 0 * y[0], lambda x: 1.0, mesh.create_unit_square(4, 4), 0.1, good)
+    assert np.array_equal(h2._stratification(cells)[:, 0, 1], np.cos(c[:, 0]))
+
+
+def test_prepare_reserves_the_plan_workspace_ahead_of_solve(monkeypatch):
+    """`reserve=True` / `prepare()` create the plan and allocate its workspace for this rank's macro cells before
+    the first solve (stub plan: records the call)."""
+    made = []
+
+    class StubPlan(OraclePlan):
+        def __init__(self, dim, n, kind, device=0):
+            super().__init__(dim, n, kind)
+            self.device, self.reserved = device, []
+            made.append(self)
+
+        def reserve(self, n_cells):
+            self.reserved.append(n_cells)
+
+    monkeypatch.setattr(hmm, "MicroCellPlan", StubPlan)
+    msh, mic = mesh.create_unit_square(3, 3), mesh.create_unit_square(4, 4)
+    h = hmm.PoissonHMM(msh, lambda x, y: 1.0 + 0 * y[0], lambda x: 1.0, mic, 0.01, device=0)
+    assert not made                                   # lazily by default: nothing happens at construction time
+    h.prepare()
+    assert len(made) == 1 and made[0].reserved == [msh.num_cells]
+    h.solve()
+    assert len(made) == 1 and made[0].reserved == [msh.num_cells]   # the solve reuses the plan and allocates nothing more
+    tp = hmm.TwoPhase(lambda y: y[0] < 0.5, lambda x: 2.0 + x[0], lambda x: 1.0)
+    h2 = hmm.PoissonHMM(msh, tp, lambda x: 1.0, mic, 0.01, device=0, reserve=True)
+    assert len(made) == 2 and made[1].reserved == [msh.num_cells] and h2._plan is made[1]

@@ -1,9 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for the nested-dissection route on the C4 / C5 problem size (run on the GPU box from the repo root):
 #   tools/profile_mf.sh TAG [CELLS]
-#   pass 1: --kernel-trace --stats                                  -> profiles/TAG_mf_kernel_stats.csv
-#   pass 2-4: --pmc SQ set | FETCH_SIZE | WRITE_SIZE (counters only, separate passes, never mixed with tracing)
-#   summary: profiles/TAG_mf_pmc_summary.json (MFMA-busy fraction of the GEMM kernels, HBM bytes per cell)
+#   pass 1: --kernel-trace --stats, default streams (4)               -> profiles/TAG_mf_kernel_stats.csv
+#   pass 1b: the same on ONE stream (HOMMX_MF_STREAMS=1: kernel durations do not overlap, their sum is the wall clock)
+#                                                                     -> profiles/TAG_mf_1stream_kernel_stats.csv
+#   pass 2-4: --pmc SQ set | FETCH_SIZE | WRITE_SIZE (counters only, separate passes, never mixed with tracing; one stream, so that the
+#             dispatch order is the launch order and tools/mf_groups.py can attribute dispatches to tree levels)
+#   summary: profiles/TAG_mf_pmc_summary.json (per kernel family: time share and TFLOP/s = MFMA flops / time on ONE stream, MFMA-busy
+#            fraction, HBM bytes per cell), profiles/TAG_mf_groups.json (per tree level)
 set -e
 TAG=${1:-r03}
 CELLS=${2:-512}
@@ -11,20 +15,29 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_mf_$TAG
 rm -rf $OUT && mkdir -p $OUT profiles
 CMD="python3 tools/mf_check.py --time-only $CELLS"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats4 -o run -- $CMD > $OUT/stats4.log 2>&1
+export HOMMX_MF_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_BUSY_CU_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY -d $OUT/sq -o run -- $CMD > $OUT/sq.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o run -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o run -- $CMD > $OUT/write.log 2>&1
+unset HOMMX_MF_STREAMS
 python3 tools/pmc_summary.py $OUT/pmc_all.json $OUT/sq $OUT/fetch $OUT/write > $OUT/pmc_summary.log
+python3 tools/mf_groups.py $OUT 1 --cells $CELLS --json profiles/${TAG}_mf_groups.json > $OUT/groups.log 2>&1 || true
+cp $OUT/groups.log profiles/${TAG}_mf_groups.txt 2>/dev/null || true
 python3 - "$TAG" "$OUT" "$CELLS" <<'PY'
 import csv, glob, json, re, sys
 tag, out, cells = sys.argv[1], sys.argv[2], int(sys.argv[3])
-st = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]
+st4 = glob.glob(out + "/stats4/**/*kernel_stats.csv", recursive=True)[0]
+rows4 = list(csv.reader(open(st4)))
+open(f"profiles/{tag}_mf_kernel_stats.csv", "w").write("\n".join(",".join('"%s"' % c for c in r) for r in rows4[:16]) + "\n")
+st = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)[0]   # ONE stream: durations add up to the wall clock
 rows = list(csv.reader(open(st)))
-open(f"profiles/{tag}_mf_kernel_stats.csv", "w").write("\n".join(",".join('"%s"' % c for c in r) for r in rows[:16]) + "\n")
+open(f"profiles/{tag}_mf_1stream_kernel_stats.csv", "w").write("\n".join(",".join('"%s"' % c for c in r) for r in rows[:16]) + "\n")
 k = json.load(open(out + "/pmc_all.json"))["kernels"]
 fam = lambda n: ("gemm_gather" if "true>" in n and "k_gemm_tile" in n else "gemm" if "k_gemm_tile" in n else "leaf_inverse" if "leaf_inverse" in n
-                 else "build" if "k_mf_build" in n else "pad" if "k_mf_pad" in n else "assembly" if ("k_assemble" in n or "k_c0" in n) else None)
+                 else "front_fused" if "k_mf_front" in n else "build" if "k_mf_build" in n else "pad" if "k_mf_pad" in n
+                 else "assembly" if ("k_assemble" in n or "k_c0" in n) else None)
 agg = {}
 for name, e in k.items():
     f = fam(name)
@@ -39,9 +52,9 @@ tot_ns = sum(float(r[2]) for r in rows[1:] if fam(r[0]))
 res = {"command": f"tools/profile_mf.sh {tag} {cells}: rocprofv3 (kernel trace; then --pmc SQ set, FETCH_SIZE, WRITE_SIZE in separate passes) -- "
                   f"python3 tools/mf_check.py --time-only {cells}  (3D elasticity, 16^3 micro cells, two solves of {cells} cells)",
        "cells_per_solve": cells, "kernel_time_ms_per_solve": tot_ns / 2e6,
-       "note": "the route runs two to four pieces of a chunk side by side on as many streams (HOMMX_MF_STREAMS=1: one): kernel durations "
-               "overlap, so their sum (kernel_time_ms_per_solve, time_us_per_cell) is several times the wall clock and small serial kernels "
-               "stretch most; counters are unaffected",
+       "note": "times, time shares and TFLOP/s are of the ONE-stream run (HOMMX_MF_STREAMS=1: kernel durations do not overlap and add up to the "
+               "wall clock; TAG_mf_1stream_kernel_stats.csv); the default runs two to four pieces of a chunk side by side on as many streams, "
+               "where durations overlap (TAG_mf_kernel_stats.csv); counters do not depend on the streams",
        "families": {}}
 for f, a in agg.items():
     t_ns = sum(float(r[2]) for r in rows[1:] if fam(r[0]) == f)
@@ -49,6 +62,7 @@ for f, a in agg.items():
     if "SQ_INSTS_MFMA" in a:
         e["mfma_per_cell"] = a["SQ_INSTS_MFMA"] / solves
         e["mfma_flops_per_cell"] = a["SQ_INSTS_MFMA"] / solves * 2048.0
+        e["tflops_one_stream"] = e["mfma_flops_per_cell"] / (e["time_us_per_cell"] * 1e-6) / 1e12 if e["time_us_per_cell"] > 0 else 0.0
         e["valu_per_cell"] = a.get("SQ_INSTS_VALU", 0.0) / solves
     if a.get("SQ_BUSY_CU_CYCLES"):
         e["mfma_busy_fraction_of_simd_cycles"] = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * a["SQ_BUSY_CU_CYCLES"])
