@@ -1,0 +1,304 @@
+// mf_front.hip -- the register-resident front kernel of the nested-dissection route (see mf_front.h) and its launcher; a translation unit of
+// its own because its fully unrolled instantiations take minutes to compile.
+#include "mf_front.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "sweep_acc.h"
+
+namespace hommx {
+
+// compile-time loop: the tiles of a wave are separate registers, never an indexed array (a loop the compiler declines to unroll would send
+// the whole front to scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void mff_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    mff_for<I + 1, N>(f);
+  }
+}
+
+// upper tiles are numbered column by column, e = b (b + 1) / 2 + a (a <= b): the number of a tile does not depend on the size of the front,
+// so a one-wave workgroup (tile e = register set e) knows (a, b) of every register set at compile time
+constexpr int mff_col(int e) {
+  int b = 0;
+  while ((b + 1) * (b + 2) / 2 <= e) ++b;
+  return b;
+}
+constexpr int mff_row(int e) { return e - mff_col(e) * (mff_col(e) + 1) / 2; }
+
+template <int NW>
+__device__ __forceinline__ void mff_sync() {
+  if constexpr (NW == 1) SyncWave::sync();
+  else __syncthreads();
+}
+
+// BS unknowns per node; NW waves; TMAX: most tiles per dimension; TPW: most tiles per wave (>= ceil(TMAX (TMAX + 1) / 2 / NW)); MINB: waves
+// per SIMD the register allocation must leave room for (small fronts are bound by the latency of their dependent loads and pivot chains: what
+// hides it is the number of fronts in flight)
+template <int BS, int NW, int TMAX, int TPW, int MINB>
+__global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
+                                                      double* __restrict__ arena, long long nc, long long batch0, int nn, int ncode, int t,
+                                                      int32_t* __restrict__ info, int stepcode) {
+  typedef accl::v4d v4d;
+  constexpr int NU = TMAX * 16;
+  constexpr int YSZ = NW == 1 ? 8 : (TMAX * 256 > NW * 272) ? TMAX * 256 : NW * 272;  // one wave: Y' stays in registers
+  __shared__ double Qp[TMAX * 256];   // panel tiles (p, b): E_b^T, one dense 16 x 16 k-major tile per column block
+  __shared__ double Yp[YSZ];          // Y'_a = -N E_a^T per row block; at the end: per-wave 16 x 17 transpose scratch
+  __shared__ double ubuf[NW * 64];    // pivot-row buffers of the sweeps, per wave
+  __shared__ int s_upos[2 * NU];
+  __shared__ int s_gnode[NU];         // global node of a real unknown; -1: padding; -2 - m: border row m
+  constexpr int MFF_CODE_LDS = NW == 1 ? 1024 : 4096;  // stencil-code tables up to this many bytes are staged in LDS (as 32-bit words)
+  __shared__ int32_t s_code32[MFF_CODE_LDS / 4];
+  const int8_t* s_code = reinterpret_cast<const int8_t*>(s_code32);
+  const int tid = threadIdx.x, l = tid & 63, j = l & 15, k = l >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = g.T, P = g.P, ntiles = g.ntiles, s16 = g.s16, s0 = g.ns * BS;
+  auto mm = [](double x, double y, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); };
+
+  // ONE front per workgroup (a grid-stride loop over fronts invites the compiler to hoist the per-tile index arithmetic of all tiles out of
+  // it -- more registers than the front itself; big batches are launched in pieces by the host)
+  {
+    const long long batch = batch0 + blockIdx.x;
+    const long long cell = batch / g.nf;
+    const int f = (int)(batch % g.nf);
+    const int32_t* nodes = g.nodes + (long long)f * g.nloc;
+    const int8_t* gcode = g.code + (long long)f * g.nloc * g.ns;
+    const int ncodes = g.nloc * g.ns;
+    const bool code_lds = ncodes <= MFF_CODE_LDS;
+    if (code_lds) {  // tables are 4-byte aligned per front when nloc * ns is a multiple of 4; otherwise byte by byte
+      if ((((long long)f * ncodes) & 3) == 0 && (reinterpret_cast<uintptr_t>(g.code) & 3) == 0) {
+        const int32_t* g32 = reinterpret_cast<const int32_t*>(gcode);
+        for (int q = tid; q < (ncodes + 3) / 4; q += 64 * NW) s_code32[q] = g32[q];  // the word behind the table belongs to the next front's (or to the allocation's slack)
+      } else {
+        int8_t* sc = reinterpret_cast<int8_t*>(s_code32);
+        for (int q = tid; q < ncodes; q += 64 * NW) sc[q] = gcode[q];
+      }
+    }
+    // ---- tables of this front into LDS
+    for (int u = tid; u < 16 * T; u += 64 * NW) {
+      int gn = -1;
+      if (u < s0) gn = nodes[u / BS];
+      else if (u >= s16) {
+        const int p = u - s16;
+        if (p < g.rb) gn = nodes[g.ns + p / BS];
+        else if (p < g.rb + MFF_BORDER) gn = -2 - (p - g.rb);
+      }
+      s_gnode[u] = gn;
+      s_upos[u] = g.upos[((long long)f * 2) * (16 * T) + u];
+      s_upos[NU + u] = g.upos[((long long)f * 2 + 1) * (16 * T) + u];
+    }
+    const MfChild ch0 = g.child[f * 2], ch1 = g.child[f * 2 + 1];
+    const double* U0 = arena + nc * ch0.offF + ((cell * ch0.nf + ch0.fidx) * (long long)ch0.L + ch0.sp) * ch0.L + ch0.sp;
+    const double* U1 = arena + nc * ch1.offF + ((cell * ch1.nf + ch1.fidx) * (long long)ch1.L + ch1.sp) * ch1.L + ch1.sp;
+    const double* Kc = Kst + cell * (long long)ncode * BS * BS * nn;
+    const double* Bc = Brhs + cell * (long long)t * BS * nn;
+    mff_sync<NW>();
+
+    // ---- 1. build: acc[tt] = upper tile e = w + tt NW; lane (k, j), register r: entry (row 16 a + 4 r + k, column 16 b + j).
+    // Branch-free: every entry issues its (at most three) loads unconditionally -- an absent contribution reads a valid dummy address
+    // and is dropped by a select -- so that the (up to twelve) loads of a tile are in flight together; with a branch per contribution
+    // a front's build is a chain of dozens of dependent memory round trips.
+    v4d acc[TPW];
+    mff_for<0, TPW>([&](auto tc) {
+      constexpr int tt = decltype(tc)::value;
+      acc[tt] = v4d{0.0, 0.0, 0.0, 0.0};
+      const int e = w + tt * NW;
+      if (e >= ntiles) return;
+      int a, b;
+      if constexpr (NW == 1) { a = mff_row(tt); b = mff_col(tt); }
+      else { const int ab = g.tilemap[e]; a = ab >> 8; b = ab & 255; }
+      if (!g.has_children && a >= P) return;  // leaf fronts: the boundary block starts from zero
+      const int uc = 16 * b + j;
+      const int gc = s_gnode[uc], p0c = s_upos[uc], p1c = s_upos[NU + uc];
+      double ident[4];
+      const double* pk[4];
+      bool okk[4], ok0[4], ok1[4];
+      long long o0[4], o1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ur = 16 * a + 4 * r + k;
+        const int gr = s_gnode[ur], p0r = s_upos[ur], p1r = s_upos[NU + ur];
+        // (lo, hi) by elimination order; entries are symmetric
+        const bool sw = ur > uc;
+        const int ulo = sw ? uc : ur, uhi = sw ? ur : uc;
+        const int glo = sw ? gc : gr, ghi = sw ? gr : gc;
+        const bool pad_s = ulo >= s0 && ulo < s16;               // identity padding of the eliminated block
+        ident[r] = (pad_s && uhi == ulo) ? 1.0 : 0.0;
+        const bool live = !pad_s && glo != -1 && ghi != -1;
+        const bool elim = live && ulo < s0;                      // the column unknown is eliminated here: stencil entry / canonical load
+        const int nlo = ulo / BS, blo = ulo - nlo * BS;
+        const bool real_hi = ghi >= 0;
+        const int nhi = uhi < s0 ? uhi / BS : g.ns + (uhi - s16) / BS;
+        const int ahi = uhi < s0 ? uhi - nhi * BS : (uhi - s16) - (nhi - g.ns) * BS;
+        const int ci = (elim && real_hi) ? nhi * g.ns + nlo : 0;
+        const int cd = code_lds ? s_code[ci] : gcode[ci];
+        const bool okK = elim && real_hi && cd >= 0;
+        const int m = -2 - ghi;
+        const bool okB = elim && !real_hi && m < t;
+        const long long offK = okK ? (((long long)cd * BS + ahi) * BS + blo) * nn + ghi : 0;
+        const long long offB = okB ? ((long long)m * BS + blo) * nn + glo : 0;
+        pk[r] = okB ? Bc + offB : Kc + offK;
+        okk[r] = okK || okB;
+        const int l0 = sw ? p0c : p0r, h0 = sw ? p0r : p0c, l1 = sw ? p1c : p1r, h1 = sw ? p1r : p1c;
+        ok0[r] = live && ch0.valid && l0 >= 0 && h0 >= 0;
+        ok1[r] = live && ch1.valid && l1 >= 0 && h1 >= 0;
+        o0[r] = ok0[r] ? (long long)(h0 > l0 ? h0 : l0) * ch0.L + (h0 > l0 ? l0 : h0) : 0;
+        o1[r] = ok1[r] ? (long long)(h1 > l1 ? h1 : l1) * ch1.L + (h1 > l1 ? l1 : h1) : 0;
+      }
+      double vk[4], v0[4], v1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vk[r] = *pk[r];
+      if (g.has_children) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = U0[o0[r]];
+          v1[r] = U1[o1[r]];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = ident[r] + (okk[r] ? vk[r] : 0.0);
+        if (g.has_children) v += (ok0[r] ? v0[r] : 0.0) + (ok1[r] ? v1[r] : 0.0);
+        acc[tt][r] = v;
+      }
+      // one tile's loads at a time: without this fence the scheduler hoists the loads of ALL tiles to the top, which costs more registers
+      // (pointers, flags) than the front itself and leaves one wave per SIMD
+      __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- 2. elimination in panels of 16
+    int bad = 0;
+    for (int p = 0; p < P; ++p) {
+      mff_for<0, TPW>([&](auto tc) {
+        constexpr int tt = decltype(tc)::value;
+        const int e = w + tt * NW;
+        if (e < ntiles) {
+          int a, b;
+          if constexpr (NW == 1) { a = mff_row(tt); b = mff_col(tt); }
+          else { const int ab = g.tilemap[e]; a = ab >> 8; b = ab & 255; }
+          if (a == p) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Qp[b * 256 + (4 * r + k) * 16 + j] = acc[tt][r];
+          }
+        }
+      });
+      mff_sync<NW>();
+      // every wave inverts the diagonal tile itself (no broadcast of N, no second barrier): T = -D, all pivots negative
+      double nm[1][1][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nm[0][0][r] = -Qp[p * 256 + (4 * r + k) * 16 + j];
+      accl::Sweep<16>::run(nm, ubuf + w * 64, j, k, bad);   // nm = T^-1 = -N
+      if constexpr (NW == 1) {
+        // one wave: (a, b) of every register set is a compile-time constant and Y'_a stays in registers (in the accumulator layout register q
+        // of a tile IS its k-slab q as the A operand of the transpose): no second LDS buffer, no barrier between the products
+        v4d yreg[TMAX];
+        mff_for<1, TMAX>([&](auto ac) {
+          constexpr int a = decltype(ac)::value;
+          if (a > p && a < T) {
+            v4d c = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c = mm(nm[0][0][q], Qp[a * 256 + (4 * q + k) * 16 + j], c);
+            yreg[a] = c;
+          }
+        });
+        mff_for<0, TPW>([&](auto tc) {
+          constexpr int tt = decltype(tc)::value;
+          constexpr int a = mff_row(tt), b = mff_col(tt);
+          if constexpr (a >= 1) {
+            if (a > p && b < T) {
+              v4d c = acc[tt];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) c = mm(yreg[a][q], Qp[b * 256 + (4 * q + k) * 16 + j], c);
+              acc[tt] = c;
+            }
+          }
+        });
+      } else {
+        // Y'_a = (-N) E_a^T for the row blocks a = p + 1 + w, + NW, ...:  C[k][i] = sum_l (-N)[l][k] E_a^T[l][i]
+        for (int a = p + 1 + w; a < T; a += NW) {
+          v4d c = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) c = mm(nm[0][0][q], Qp[a * 256 + (4 * q + k) * 16 + j], c);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Yp[a * 256 + (4 * r + k) * 16 + j] = c[r];
+        }
+        mff_sync<NW>();
+        // trailing tiles (a, b), p < a <= b:  acc += Y'_a^T E_b^T
+        mff_for<0, TPW>([&](auto tc) {
+          constexpr int tt = decltype(tc)::value;
+          const int e = w + tt * NW;
+          if (e < ntiles) {
+            const int ab = g.tilemap[e], a = ab >> 8, b = ab & 255;
+            if (a > p) {
+              v4d c = acc[tt];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) c = mm(Yp[a * 256 + (4 * q + k) * 16 + j], Qp[b * 256 + (4 * q + k) * 16 + j], c);
+              acc[tt] = c;
+            }
+          }
+        });
+      }
+      mff_sync<NW>();  // the next panel overwrites Qp / Yp
+    }
+
+    // ---- 3. the update matrix (lower triangle, arena layout of the group: F22 at (sp, sp), ld = L), rows up to the border
+    {
+      double* U = arena + nc * g.offF + batch * (long long)g.L * g.L + (long long)g.sp * g.L + g.sp;
+      double* tsc = NW == 1 ? Qp : Yp + w * 272;  // (one wave: Qp is free after the last panel; TMAX >= 2)
+      const int nrow = g.rb + MFF_BORDER;
+      mff_for<0, TPW>([&](auto tc) {
+        constexpr int tt = decltype(tc)::value;
+        const int e = w + tt * NW;
+        int a, b;
+        if constexpr (NW == 1) { a = mff_row(tt); b = mff_col(tt); }
+        else { const int ab = e < ntiles ? g.tilemap[e] : 0; a = ab >> 8; b = ab & 255; }
+        if (e < ntiles && a >= P) {
+          const v4d y = accl::transpose_tile(acc[tt], tsc, j, k);  // y[r] at lane (k, j) = F[row 16 b + 4 r + k][column 16 a + j]
+          const int col = 16 * a + j - s16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * b + 4 * r + k - s16;
+            if (row < nrow && col <= row) U[(long long)row * g.L + col] = y[r];
+          }
+        }
+      });
+    }
+    if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
+  }
+}
+
+
+void launch_mf_front(const MfFrontDev& g, int bs, const double* Kst, const double* Brhs, double* arena, long long nc, long long nbatch, int nn,
+                     int ncode, int t, int32_t* info, int stepcode, hipStream_t st) {
+  // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches go in pieces of 2^21 fronts
+  for (long long b0 = 0; b0 < nbatch; b0 += 1ll << 21) {
+  const unsigned grid = (unsigned)std::min(nbatch - b0, 1ll << 21);
+#define HOMMX_MFF(BS_, NW_, TMAX_, TPW_, MINB_)                                                                                              \
+  hipLaunchKernelGGL((k_mf_front<BS_, NW_, TMAX_, TPW_, MINB_>), dim3(grid), dim3(64 * NW_), 0, st, g, Kst, Brhs, arena, nc, b0, nn, ncode, \
+                     t, info, stepcode)
+  // register budgets (waves per SIMD): 10 tiles = 80 VGPRs of matrix -> 4; 21 tiles -> 2; four waves x 9 tiles -> 3; x 20 -> 2; eight x 24 -> 2
+#ifdef MFF_ONLY_ONE  // dev builds: one instantiation (register experiments)
+#define HOMMX_MFF_BS(BS_) HOMMX_MFF(1, 1, 4, 10, 4)
+#else
+#define HOMMX_MFF_BS(BS_)                                \
+  do {                                                   \
+    if (g.T <= 4) HOMMX_MFF(BS_, 1, 4, 10, 4);           \
+    else if (g.T <= 6) HOMMX_MFF(BS_, 1, 6, 21, 2);      \
+    else if (g.T <= 8) HOMMX_MFF(BS_, 4, 8, 9, 3);       \
+    else if (g.T <= 12) HOMMX_MFF(BS_, 4, 12, 20, 2);    \
+    else HOMMX_MFF(BS_, 8, 19, 24, 2);                   \
+  } while (0)
+#endif
+  if (bs == 1) HOMMX_MFF_BS(1);
+  else if (bs == 2) HOMMX_MFF_BS(2);
+  else HOMMX_MFF_BS(3);
+#undef HOMMX_MFF_BS
+#undef HOMMX_MFF
+  }
+}
+
+}  // namespace hommx

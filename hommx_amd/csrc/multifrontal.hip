@@ -37,6 +37,7 @@
 #include "../../include/hommx_hip.h"
 #include "blocked_internal.h"
 #include "kernels.h"
+#include "mf_front.h"
 
 namespace hommx {
 
@@ -64,6 +65,12 @@ struct MfGroup {
   int32_t* d_cpos = nullptr;        // [nf][2][nloc]   position of local node in child c's boundary list, -1: not there
   int32_t* d_dpos = nullptr;        // [nf][2][rp]     unknown of child c's boundary block for boundary unknown p of this front, -1: none
   MfChild* d_child = nullptr;       // [nf][2]
+  // register-resident route of the group (mf_front.h: k_mf_front), when the whole front fits the registers of one workgroup
+  bool front = false;
+  int s16 = 0, T = 0, P = 0, ntiles = 0;   // 16-granular padded s, tiles per dimension, panels, upper tiles
+  int32_t* d_upos = nullptr;        // [nf][2][16 T]  unknown of the front -> unknown of the child's update matrix, -1: none
+  uint16_t* d_tilemap = nullptr;    // [ntiles]       a << 8 | b
+  bool has_children = false;
 };
 
 struct MfPlan {
@@ -74,6 +81,7 @@ struct MfPlan {
   long long scratch_per_cell = 0;   // doubles: inverse scratch of the largest group
   double flops_per_cell = 0.0;      // executed dense flops by the model of mf_solve (staged elimination + Schur update) on the padded sizes
   int stage = 192;                  // HOMMX_MF_STAGE: unknowns per elimination stage inside a front (0: one stage)
+  int front_max_t = MFF_MAX_T;      // HOMMX_MF_FRONT: most 16-tiles per dimension of a front that takes k_mf_front (0: never; at most MFF_MAX_T)
   bool keep = false;                // corrector plan: every front keeps its own place in the arena (the back substitution reads N and X of all of them)
   long long vbuf_per_cell = 0;      // doubles: solution vectors of the largest group, [nf][MF_BORDER][L] (corrector plan)
   // chunk buffers
@@ -228,6 +236,8 @@ void mf_plan_destroy(MfPlan* p) {
     if (g.d_cpos) (void)hipFree(g.d_cpos);
     if (g.d_dpos) (void)hipFree(g.d_dpos);
     if (g.d_child) (void)hipFree(g.d_child);
+    if (g.d_upos) (void)hipFree(g.d_upos);
+    if (g.d_tilemap) (void)hipFree(g.d_tilemap);
   }
   for (double* q : {p->arena, p->scratch, p->vbuf, p->Kst, p->Brhs, p->C0})
     if (q) (void)hipFree(q);
@@ -256,6 +266,8 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
   if (const char* e = getenv("HOMMX_MF_SPLIT_DEPTH")) tb.split_depth = atoi(e);
   if (const char* e = getenv("HOMMX_MF_STAGE")) P->stage = atoi(e);
   if (const char* e = getenv("HOMMX_MF_STREAMS")) P->streams = atoi(e);
+  if (const char* e = getenv("HOMMX_MF_FRONT")) P->front_max_t = std::max(0, std::min(MFF_MAX_T, atoi(e)));
+  if (keep) P->front_max_t = 0;  // the back substitution reads N_i and X_i of every front: the corrector plan keeps them in HBM
   {
     std::vector<int> all(nn);
     for (int i = 0; i < nn; ++i) all[i] = i;
@@ -364,6 +376,13 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     mg.rp = round_up(mg.rb + MF_BORDER, 16);
     mg.L = mg.sp + mg.rp;
     mg.nf = (int)members[g].size();
+    mg.s16 = round_up(mg.ns * bs, 16);
+    mg.T = (mg.s16 + round_up(mg.rb + MF_BORDER, 16)) / 16;
+    mg.P = mg.s16 / 16;
+    mg.ntiles = mg.T * (mg.T + 1) / 2;
+    mg.has_children = !s0.children.empty();
+    // the root front pins the gauge node (k_mf_pad does that on the launch sequence): it stays there
+    mg.front = mg.T <= P->front_max_t && members[g][0] != nsn - 1 && s0.height < sn[nsn - 1].height;
     expiry[t] = t;
   }
   for (int k = 0; k < nsn; ++k)
@@ -394,7 +413,14 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
       mg.offF = place((long long)mg.nf * mg.L * mg.L, expiry[t], t);
       P->scratch_per_cell = std::max(P->scratch_per_cell, (long long)mg.nf * mg.sp * mg.sp);
       if (keep) P->vbuf_per_cell = std::max(P->vbuf_per_cell, (long long)mg.nf * MF_BORDER * mg.L);
-      {  // inverse of a stage si^3, X_i 2 si^2 below, column update 2 below rem si, Schur update s r^2 (lower tiles)
+      if (mg.front) {  // k_mf_front: per panel p of 16 pivots the sweep, T - 1 - p products Y'_a and (T - 1 - p)(T - p) / 2 tile updates of 4 MFMAs
+        double f = 0.0;
+        for (int pp = 0; pp < mg.P; ++pp) {
+          const double rest = mg.T - 1 - pp;
+          f += 2.0 * 16 * 16 * 16 + 8192.0 * (rest + rest * (rest + 1) / 2);
+        }
+        P->flops_per_cell += mg.nf * f;
+      } else {  // inverse of a stage si^3, X_i 2 si^2 below, column update 2 below rem si, Schur update s r^2 (lower tiles)
         const int nst = mf_stages(mg.sp, P->stage);
         double f = (double)mg.sp * mg.rp * mg.rp;
         int off = 0;
@@ -415,8 +441,10 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     MfGroup& mg = P->groups[t];
     const int nloc = mg.ns + mg.nr;
     std::vector<int32_t> nodes((size_t)mg.nf * nloc), cpos((size_t)mg.nf * 2 * nloc, -1), dpos((size_t)mg.nf * 2 * mg.rp, -1);
-    std::vector<int8_t> code((size_t)mg.nf * nloc * mg.ns, (int8_t)-1);
+    std::vector<int8_t> code((size_t)mg.nf * nloc * mg.ns + 4, (int8_t)-1);  // + 4: k_mf_front stages the tables word by word
     std::vector<MfChild> child((size_t)mg.nf * 2);
+    const int NUf = 16 * mg.T;
+    std::vector<int32_t> upos(mg.front ? (size_t)mg.nf * 2 * NUf : 0, -1);
     for (int f = 0; f < mg.nf; ++f) {
       const SN& s = sn[members[g][f]];
       int32_t* nd = &nodes[(size_t)f * nloc];
@@ -459,6 +487,14 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
           dp[p] = q < 0 ? -1 : q * bs + p % bs;
         }
         for (int m = 0; m < MF_BORDER; ++m) dp[mg.rb + m] = cg.rb + m;  // border row m of the child -> border row m here
+        if (mg.front) {  // the same maps per UNKNOWN of the 16-granular front: eliminated unknowns, boundary unknowns, border rows
+          int32_t* up = &upos[((size_t)f * 2 + slot) * NUf];
+          for (int u = 0; u < mg.ns * bs; ++u) {
+            const int q = cpos[((size_t)f * 2 + slot) * nloc + u / bs];
+            up[u] = q < 0 ? -1 : q * bs + u % bs;
+          }
+          for (int p = 0; p < mg.rb + MF_BORDER; ++p) up[mg.s16 + p] = dp[p];
+        }
       }
       if (s.children.size() > 2) {
         g_berr = "multifrontal plan: more than two children";
@@ -468,8 +504,12 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
       if (members[g][f] == nsn - 1) mg.pinpos = local[nn - 1];
       for (int i = 0; i < nloc; ++i) local[nd[i]] = -1;
     }
+    std::vector<uint16_t> tilemap;
+    if (mg.front)
+      for (int b = 0; b < mg.T; ++b)   // column by column: e = b (b + 1) / 2 + a, independent of T (mf_front.hip)
+        for (int a = 0; a <= b; ++a) tilemap.push_back((uint16_t)(a << 8 | b));
     if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_dpos, dpos) ||
-        upload(&mg.d_child, child)) {
+        upload(&mg.d_child, child) || upload(&mg.d_upos, upos) || upload(&mg.d_tilemap, tilemap)) {
       mf_plan_destroy(P);
       return HOMMX_EHIP;
     }
@@ -478,7 +518,8 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     fprintf(stderr, "[hommx multifrontal] n = %d, bs = %d: %d fronts in %d groups, arena %.1f MB + scratch %.1f MB per cell, %.2f GFLOP per cell\n",
             n, bs, nsn, ng, 8e-6 * P->arena_per_cell, 8e-6 * P->scratch_per_cell, 1e-9 * P->flops_per_cell);
     for (const MfGroup& mg : P->groups)
-      fprintf(stderr, "   height %d: %3d fronts  s = %4d (%4d)  r = %4d (%4d)\n", mg.height, mg.nf, mg.ns * bs, mg.sp, mg.rb, mg.rp);
+      fprintf(stderr, "   height %d: %3d fronts  s = %4d (%4d)  r = %4d (%4d)%s\n", mg.height, mg.nf, mg.ns * bs, mg.sp, mg.rb, mg.rp,
+              mg.front ? "  [k_mf_front]" : "");
   }
   *out = P;
   return 0;
@@ -767,6 +808,12 @@ void mf_group_step(BlockedWorkspace* ws, MfPlan* P, const MfHalf& h, const MfGro
   const double* Kst = P->Kst + h.base * G.ncode * bs * bs * G.nn;
   const double* Brhs = P->Brhs + h.base * G.t * bs * G.nn;
   const long long nb = nc * mg.nf;  // matrices in this batch
+  if (mg.front) {  // the whole group in ONE launch: fronts live in registers (mf_front.h)
+    MfFrontDev fd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.s16, mg.T, mg.P, mg.ntiles, mg.has_children ? 1 : 0, mg.offF,
+                  mg.d_nodes, mg.d_code, mg.d_upos, mg.d_child, mg.d_tilemap};
+    launch_mf_front(fd, bs, Kst, Brhs, arena, nc, nb, G.nn, G.ncode, G.t, d_info ? d_info + h.c0 : nullptr, gi, st);
+    return;
+  }
   MfGroupDev gd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.offF, mg.d_nodes, mg.d_code, mg.d_cpos, mg.d_child};
   const int jblocks = (mg.ns * bs + 63) / 64;  // 64 column unknowns per wave
   int pshift = 0;  // rows of a narrow front packed into one wave (k_mf_build)
