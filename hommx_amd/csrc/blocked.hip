@@ -954,13 +954,21 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   // block b > 64, i.e. everything the one-launch kernels do not take: 2D scalar n = 80: +51 %, 2D elasticity n = 36: +92 %, 3D elasticity
   // n = 5: +68 %, n = 16: +76 %, scalar 3D n = 9: +18 % (it lost 10 % there before the build kernel batched its loads and the route ran on
   // two streams)
-  ws->mf_min_b = 65;
-  if (const char* e = getenv("HOMMX_MF_MIN_B")) ws->mf_min_b = atoi(e);
+  // Round 4: with the register-resident front kernel (mf_front.hip: one launch per tree level, fronts never leave the registers) the tree
+  // also beats the LDS kernel of csrc/small_fused.h on 2D meshes with 48 < b <= 64: 2D Poisson 64^2 175 k -> 256 k solves/s, 2D elasticity
+  // 32^2 320 k -> 336 k; it loses on 3D Poisson 8^3 (1.25 M -> 0.79 M: few, larger fronts) and against the one-wave kernel (b <= 48).
+  ws->mf_min_b = dim == 2 ? 49 : 65;
+  bool mf_env = false;
+  if (const char* e = getenv("HOMMX_MF_MIN_B")) {
+    ws->mf_min_b = atoi(e);
+    mf_env = true;
+  }
   if (const char* e = getenv("HOMMX_MF_G128_MIN_K")) ws->mf_gather128_min_k = atoi(e);
   ws->mf_no_border_split = getenv("HOMMX_MF_NO_BORDER_SPLIT") != nullptr;
   if (const char* e = getenv("HOMMX_MF_CORR")) ws->mf_corr = atoi(e) != 0;
   if (const char* e = getenv("HOMMX_TILE_SB")) ws->tile_sb = atoi(e);
-  if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && (G.b > 64 || !ws->small_fused)) {
+  // (a threshold from the environment below 65 takes effect only together with HOMMX_NO_SMALL_FUSED: A/B runs)
+  if (ws->mf_min_b > 0 && G.b >= ws->mf_min_b && (G.b > 64 || !ws->small_fused || (!mf_env && G.b > 48))) {
     if (int rc = mf_plan_create(&ws->mf, G)) {
       delete ws;
       return rc;

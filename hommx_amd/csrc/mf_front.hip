@@ -37,9 +37,9 @@ __device__ __forceinline__ void mff_sync() {
 }
 
 // BS unknowns per node; NW waves; TMAX: most tiles per dimension; TPW: most tiles per wave (>= ceil(TMAX (TMAX + 1) / 2 / NW)); MINB: waves
-// per SIMD the register allocation must leave room for (small fronts are bound by the latency of their dependent loads and pivot chains: what
+// per SIMD the register allocation must leave room for; FENCE: tiles whose build loads are in flight together (small fronts are bound by the latency of their dependent loads and pivot chains: what
 // hides it is the number of fronts in flight)
-template <int BS, int NW, int TMAX, int TPW, int MINB>
+template <int BS, int NW, int TMAX, int TPW, int MINB, int FENCE>
 __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
                                                       double* __restrict__ arena, long long nc, long long batch0, int nn, int ncode, int t,
                                                       int32_t* __restrict__ info, int stepcode) {
@@ -49,8 +49,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
   __shared__ double Qp[TMAX * 256];   // panel tiles (p, b): E_b^T, one dense 16 x 16 k-major tile per column block
   __shared__ double Yp[YSZ];          // Y'_a = -N E_a^T per row block; at the end: per-wave 16 x 17 transpose scratch
   __shared__ double ubuf[NW * 64];    // pivot-row buffers of the sweeps, per wave
-  __shared__ int s_upos[2 * NU];
+  // per unknown u of the front, so that an entry of the build costs a few LDS reads and adds instead of divisions and 64-bit products:
+  __shared__ int s_upos[2 * NU];      // unknown of child slot c's update matrix, -1: none
   __shared__ int s_gnode[NU];         // global node of a real unknown; -1: padding; -2 - m: border row m
+  __shared__ int s_rk[NU];            // as the ROW of a stencil entry:    component * BS * nn + global node
+  __shared__ int s_ck[NU];            // as the COLUMN of a stencil entry: component * nn
+  __shared__ int s_n1[NU];            // local node * ns (row of the stencil-code table)
+  __shared__ int s_nl[NU];            // local node      (column of the stencil-code table; eliminated unknowns only)
   constexpr int MFF_CODE_LDS = NW == 1 ? 1024 : 4096;  // stencil-code tables up to this many bytes are staged in LDS (as 32-bit words)
   __shared__ int32_t s_code32[MFF_CODE_LDS / 4];
   const int8_t* s_code = reinterpret_cast<const int8_t*>(s_code32);
@@ -80,14 +85,25 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
     }
     // ---- tables of this front into LDS
     for (int u = tid; u < 16 * T; u += 64 * NW) {
-      int gn = -1;
-      if (u < s0) gn = nodes[u / BS];
-      else if (u >= s16) {
+      int gn = -1, node = 0, comp = 0;
+      if (u < s0) {
+        node = u / BS;
+        comp = u - node * BS;
+        gn = nodes[node];
+      } else if (u >= s16) {
         const int p = u - s16;
-        if (p < g.rb) gn = nodes[g.ns + p / BS];
-        else if (p < g.rb + MFF_BORDER) gn = -2 - (p - g.rb);
+        if (p < g.rb) {
+          node = p / BS;
+          comp = p - node * BS;
+          node += g.ns;
+          gn = nodes[node];
+        } else if (p < g.rb + MFF_BORDER) gn = -2 - (p - g.rb);
       }
       s_gnode[u] = gn;
+      s_rk[u] = comp * BS * nn + gn;
+      s_ck[u] = comp * nn;
+      s_n1[u] = node * g.ns;
+      s_nl[u] = node;
       s_upos[u] = g.upos[((long long)f * 2) * (16 * T) + u];
       s_upos[NU + u] = g.upos[((long long)f * 2 + 1) * (16 * T) + u];
     }
@@ -113,66 +129,90 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
       else { const int ab = g.tilemap[e]; a = ab >> 8; b = ab & 255; }
       if (!g.has_children && a >= P) return;  // leaf fronts: the boundary block starts from zero
       const int uc = 16 * b + j;
-      const int gc = s_gnode[uc], p0c = s_upos[uc], p1c = s_upos[NU + uc];
-      double ident[4];
-      const double* pk[4];
-      bool okk[4], ok0[4], ok1[4];
-      long long o0[4], o1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ur = 16 * a + 4 * r + k;
-        const int gr = s_gnode[ur], p0r = s_upos[ur], p1r = s_upos[NU + ur];
-        // (lo, hi) by elimination order; entries are symmetric
-        const bool sw = ur > uc;
-        const int ulo = sw ? uc : ur, uhi = sw ? ur : uc;
-        const int glo = sw ? gc : gr, ghi = sw ? gr : gc;
-        const bool pad_s = ulo >= s0 && ulo < s16;               // identity padding of the eliminated block
-        ident[r] = (pad_s && uhi == ulo) ? 1.0 : 0.0;
-        const bool live = !pad_s && glo != -1 && ghi != -1;
-        const bool elim = live && ulo < s0;                      // the column unknown is eliminated here: stencil entry / canonical load
-        const int nlo = ulo / BS, blo = ulo - nlo * BS;
-        const bool real_hi = ghi >= 0;
-        const int nhi = uhi < s0 ? uhi / BS : g.ns + (uhi - s16) / BS;
-        const int ahi = uhi < s0 ? uhi - nhi * BS : (uhi - s16) - (nhi - g.ns) * BS;
-        const int ci = (elim && real_hi) ? nhi * g.ns + nlo : 0;
-        const int cd = code_lds ? s_code[ci] : gcode[ci];
-        const bool okK = elim && real_hi && cd >= 0;
-        const int m = -2 - ghi;
-        const bool okB = elim && !real_hi && m < t;
-        const long long offK = okK ? (((long long)cd * BS + ahi) * BS + blo) * nn + ghi : 0;
-        const long long offB = okB ? ((long long)m * BS + blo) * nn + glo : 0;
-        pk[r] = okB ? Bc + offB : Kc + offK;
-        okk[r] = okK || okB;
-        const int l0 = sw ? p0c : p0r, h0 = sw ? p0r : p0c, l1 = sw ? p1c : p1r, h1 = sw ? p1r : p1c;
-        ok0[r] = live && ch0.valid && l0 >= 0 && h0 >= 0;
-        ok1[r] = live && ch1.valid && l1 >= 0 && h1 >= 0;
-        o0[r] = ok0[r] ? (long long)(h0 > l0 ? h0 : l0) * ch0.L + (h0 > l0 ? l0 : h0) : 0;
-        o1[r] = ok1[r] ? (long long)(h1 > l1 ? h1 : l1) * ch1.L + (h1 > l1 ? l1 : h1) : 0;
-      }
-      double vk[4], v0[4], v1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vk[r] = *pk[r];
-      if (g.has_children) {
+      const int p0c = s_upos[uc], p1c = s_upos[NU + uc];
+      const int L0 = ch0.L, L1 = ch1.L;
+      if (a >= P) {
+        // both unknowns on the boundary: nothing but the children's update matrices (upos is -1 for padding and for an absent child)
+        int o0[4], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v0[r] = U0[o0[r]];
-          v1[r] = U1[o1[r]];
+          const int ur = 16 * a + 4 * r + k;
+          const int p0r = s_upos[ur], p1r = s_upos[NU + ur];
+          const int h0 = p0r > p0c ? p0r : p0c, l0 = p0r > p0c ? p0c : p0r, h1 = p1r > p1c ? p1r : p1c, l1 = p1r > p1c ? p1c : p1r;
+          o0[r] = l0 >= 0 ? h0 * L0 + l0 : -1;
+          o1[r] = l1 >= 0 ? h1 * L1 + l1 : -1;
+        }
+        double v0[4], v1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = U0[o0[r] >= 0 ? o0[r] : 0];
+          v1[r] = U1[o1[r] >= 0 ? o1[r] : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tt][r] = (o0[r] >= 0 ? v0[r] : 0.0) + (o1[r] >= 0 ? v1[r] : 0.0);
+      } else {
+        // the row block is eliminated here: stencil entries / canonical loads (+ children).  Off the diagonal tiles the row unknown is the
+        // earlier one (lo); inside a diagonal tile either order occurs
+        const int gc = s_gnode[uc], rkc = s_rk[uc], ckc = s_ck[uc], n1c = s_n1[uc], nlc = s_nl[uc];
+        const int KS = BS * BS * nn;
+        double ident[4];
+        const double* pk[4];
+        bool okk[4];
+        int o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ur = 16 * a + 4 * r + k;
+          const int gr = s_gnode[ur], p0r = s_upos[ur], p1r = s_upos[NU + ur];
+          const bool sw = a == b && ur > uc;
+          const int ulo = sw ? uc : ur, uhi = sw ? ur : uc;
+          const int glo = sw ? gc : gr, ghi = sw ? gr : gc;
+          const int cklo = sw ? ckc : s_ck[ur], nllo = sw ? nlc : s_nl[ur];
+          const int rkhi = sw ? s_rk[ur] : rkc, n1hi = sw ? s_n1[ur] : n1c;
+          const bool pad_s = ulo >= s0;                           // (ulo < s16 here) identity padding of the eliminated block
+          ident[r] = (pad_s && uhi == ulo) ? 1.0 : 0.0;
+          const bool elim = !pad_s && ghi != -1;                  // a real eliminated column unknown against a real unknown or a border row
+          const bool real_hi = ghi >= 0;
+          const int ci = (elim && real_hi) ? n1hi + nllo : 0;
+          const int cd = code_lds ? s_code[ci] : gcode[ci];
+          const bool okK = elim && real_hi && cd >= 0;
+          const int m = -2 - ghi;
+          const bool okB = elim && !real_hi && m < t;
+          pk[r] = okB ? Bc + (m * BS * nn + cklo + glo) : Kc + (okK ? cd * KS + rkhi + cklo : 0);
+          okk[r] = okK || okB;
+          const int h0 = p0r > p0c ? p0r : p0c, l0 = p0r > p0c ? p0c : p0r, h1 = p1r > p1c ? p1r : p1c, l1 = p1r > p1c ? p1c : p1r;
+          o0[r] = (elim && l0 >= 0) ? h0 * L0 + l0 : -1;
+          o1[r] = (elim && l1 >= 0) ? h1 * L1 + l1 : -1;
+        }
+        double vk[4], v0[4], v1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vk[r] = *pk[r];
+        if (g.has_children) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v0[r] = U0[o0[r] >= 0 ? o0[r] : 0];
+            v1[r] = U1[o1[r] >= 0 ? o1[r] : 0];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = ident[r] + (okk[r] ? vk[r] : 0.0);
+          if (g.has_children) v += (o0[r] >= 0 ? v0[r] : 0.0) + (o1[r] >= 0 ? v1[r] : 0.0);
+          acc[tt][r] = v;
         }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double v = ident[r] + (okk[r] ? vk[r] : 0.0);
-        if (g.has_children) v += (ok0[r] ? v0[r] : 0.0) + (ok1[r] ? v1[r] : 0.0);
-        acc[tt][r] = v;
-      }
-      // one tile's loads at a time: without this fence the scheduler hoists the loads of ALL tiles to the top, which costs more registers
-      // (pointers, flags) than the front itself and leaves one wave per SIMD
-      __builtin_amdgcn_sched_barrier(0);
+      // the loads of FENCE tiles at a time: without a fence the scheduler hoists the loads of ALL tiles to the top, which costs more
+      // registers (pointers, flags) than the front itself and leaves one wave per SIMD
+      if constexpr ((tt + 1) % FENCE == 0) __builtin_amdgcn_sched_barrier(0);
     });
 
     // ---- 2. elimination in panels of 16
     int bad = 0;
-    for (int p = 0; p < P; ++p) {
+#if defined(MFF_PHASE) && MFF_PHASE < 2
+    const int Pn = 0;
+#else
+    const int Pn = P;
+#endif
+    for (int p = 0; p < Pn; ++p) {
       mff_for<0, TPW>([&](auto tc) {
         constexpr int tt = decltype(tc)::value;
         const int e = w + tt * NW;
@@ -245,6 +285,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
       mff_sync<NW>();  // the next panel overwrites Qp / Yp
     }
 
+#if !defined(MFF_PHASE) || MFF_PHASE >= 3 || MFF_PHASE == 1
     // ---- 3. the update matrix (lower triangle, arena layout of the group: F22 at (sp, sp), ld = L), rows up to the border
     {
       double* U = arena + nc * g.offF + batch * (long long)g.L * g.L + (long long)g.sp * g.L + g.sp;
@@ -267,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
         }
       });
     }
+#endif
     if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
   }
 }
@@ -277,20 +319,26 @@ void launch_mf_front(const MfFrontDev& g, int bs, const double* Kst, const doubl
   // a launch holds at most 2^32 - 1 work-items (AQL grid size): big batches go in pieces of 2^21 fronts
   for (long long b0 = 0; b0 < nbatch; b0 += 1ll << 21) {
   const unsigned grid = (unsigned)std::min(nbatch - b0, 1ll << 21);
-#define HOMMX_MFF(BS_, NW_, TMAX_, TPW_, MINB_)                                                                                              \
-  hipLaunchKernelGGL((k_mf_front<BS_, NW_, TMAX_, TPW_, MINB_>), dim3(grid), dim3(64 * NW_), 0, st, g, Kst, Brhs, arena, nc, b0, nn, ncode, \
-                     t, info, stepcode)
+#define HOMMX_MFF(BS_, NW_, TMAX_, TPW_, MINB_, FENCE_)                                                                                      \
+  hipLaunchKernelGGL((k_mf_front<BS_, NW_, TMAX_, TPW_, MINB_, FENCE_>), dim3(grid), dim3(64 * NW_), 0, st, g, Kst, Brhs, arena, nc, b0, nn, \
+                     ncode, t, info, stepcode)
   // register budgets (waves per SIMD): 10 tiles = 80 VGPRs of matrix -> 4; 21 tiles -> 2; four waves x 9 tiles -> 3; x 20 -> 2; eight x 24 -> 2
 #ifdef MFF_ONLY_ONE  // dev builds: one instantiation (register experiments)
-#define HOMMX_MFF_BS(BS_) HOMMX_MFF(1, 1, 4, 10, 4)
+#define HOMMX_MFF_BS(BS_) HOMMX_MFF(3, 8, 19, 24, 2, 3)
+#elif defined(MFF_DEV_BS3)  // dev builds: the two multi-wave variants of three unknowns per node only (phase timing, seconds to compile)
+#define HOMMX_MFF_BS(BS_)                                \
+  do {                                                   \
+    if (g.T <= 12) HOMMX_MFF(3, 4, 12, 20, 2, 4);        \
+    else HOMMX_MFF(3, 8, 19, 24, 2, 3);                  \
+  } while (0)
 #else
 #define HOMMX_MFF_BS(BS_)                                \
   do {                                                   \
-    if (g.T <= 4) HOMMX_MFF(BS_, 1, 4, 10, 4);           \
-    else if (g.T <= 6) HOMMX_MFF(BS_, 1, 6, 21, 2);      \
-    else if (g.T <= 8) HOMMX_MFF(BS_, 4, 8, 9, 3);       \
-    else if (g.T <= 12) HOMMX_MFF(BS_, 4, 12, 20, 2);    \
-    else HOMMX_MFF(BS_, 8, 19, 24, 2);                   \
+    if (g.T <= 4) HOMMX_MFF(BS_, 1, 4, 10, 4, 1);        \
+    else if (g.T <= 6) HOMMX_MFF(BS_, 1, 6, 21, 2, 2);   \
+    else if (g.T <= 8) HOMMX_MFF(BS_, 4, 8, 9, 3, 3);    \
+    else if (g.T <= 12) HOMMX_MFF(BS_, 4, 12, 20, 2, 4); \
+    else HOMMX_MFF(BS_, 8, 19, 24, 2, 3);                \
   } while (0)
 #endif
   if (bs == 1) HOMMX_MFF_BS(1);

@@ -54,7 +54,11 @@ extern "C" {
  *   HOMMX_NO_H2D_OVERLAP   any value: hommx_solve_batch copies the whole coefficient stream before the first kernel
  *   HOMMX_NO_SMALL_FUSED   any value: plane blocks b <= 64 take the HBM-resident kernels instead of the one-launch kernels
  *   HOMMX_MF_MIN_B         smallest plane block b routed to the nested-dissection (multifrontal) elimination instead of the plane
- *                          elimination (default: 65, i.e. every plane block the one-launch kernels do not take; 0: never)
+ *                          elimination (default: 65 in 3D, 49 in 2D, i.e. every plane block the one-launch kernels do not take or lose
+ *                          on; 0: never; a value below 65 from the environment needs HOMMX_NO_SMALL_FUSED as well)
+ *   HOMMX_MF_FRONT         most 16 x 16 tiles per dimension of a front that is eliminated by the register-resident front kernel
+ *                          (csrc/mf_front.hip: one launch per tree level) instead of the build / inverse / GEMM launch sequence
+ *                          (default and maximum 19; 0: never)
  *   HOMMX_MF_STREAMS       1: the nested-dissection route runs on the caller's stream alone (default 4: every chunk as two to four pieces side
  *                          by side on the caller's stream and plan-owned ones; the caller's stream waits for all, results are bitwise equal)
  *   HOMMX_MF_CORR          0: hommx_solve_batch_correctors of a nested-dissection plan runs the plane elimination (default: back substitution
@@ -93,7 +97,7 @@ int hommx_plan_reserve(hommx_plan* plan, int64_t n_cells);
 /* Shape queries: elements per micro mesh (2 n^2 / 6 n^3), coefficient doubles per element,
  * t = size of the effective tensor (d for Poisson, d(d+1)/2 for elasticity), the descriptor fields, and the name of the
  * kernel route the plan's effective-tensor solves take: "fused2d" (2D scalar Poisson, n <= 32), "small_wave" (plane block
- * b <= 48: one wavefront per cell), "small_fused" (48 < b <= 64: LDS), "multifrontal" (large plane blocks, e.g. 3D elasticity
+ * b <= 48: one wavefront per cell), "small_fused" (3D meshes with 48 < b <= 64: LDS), "multifrontal" (plane blocks b > 64 and 2D meshes with b > 48, e.g. 3D elasticity
  * from 5^3 micro cells: nested dissection, batched fronts) or "blocked" (everything else: plane elimination; also the corrector entry point of plans whose tensors take a one-launch route). */
 int32_t hommx_plan_dim(const hommx_plan* plan);
 int32_t hommx_plan_device(const hommx_plan* plan);

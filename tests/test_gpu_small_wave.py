@@ -31,7 +31,8 @@ CASES = [
     ("elasticity", 3, 4),         # b 48, t 6: NT 3, slab form
     ("poisson_matrix", 2, 47),    # b 47, t 2: NT 3, slab form (b + t = 49)
     ("poisson", 3, 7),            # b 49: LDS kernel (48 < b <= 64, csrc/small_fused.h), 13 of 16 k-slabs
-    ("elasticity", 2, 28),        # b 56: LDS kernel, 14 of 16 k-slabs
+    ("elasticity", 2, 28),        # b 56 on a 2D mesh: nested dissection since round 4 (register-resident fronts, csrc/mf_front.hip)
+    ("poisson", 3, 8),            # b 64: LDS kernel, all 16 k-slabs
 ]
 
 
@@ -77,7 +78,8 @@ def test_wave_kernel_matches_oracle(kind, dim, n):
     from oracle import hommx_oracle as O
 
     p = MicroCellPlan(dim, n, kind)
-    assert p.kernel == ("small_wave" if _plane_block(kind, dim, n) <= 48 else "small_fused")
+    b = _plane_block(kind, dim, n)
+    assert p.kernel == ("small_wave" if b <= 48 else "multifrontal" if dim == 2 else "small_fused")
     coef, M = _inputs(p, kind, dim, 5, 3)
     A, info = p.solve(coef, M, return_info=True)
     assert not info.any()
