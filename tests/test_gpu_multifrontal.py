@@ -309,3 +309,56 @@ def test_random_sizes_kinds_contrasts_against_the_oracle():
             assert not info.any() and err < 1e-10, (dim, kind, n, contrast, err)
         print("ok")
     """, {"HOMMX_MF_MIN_B": "65"})
+
+
+_FRONT_CASES = [("poisson", 2, 64), ("poisson", 2, 100), ("elasticity", 2, 28), ("elasticity", 2, 40), ("poisson_matrix", 2, 72),
+                ("poisson", 3, 9), ("poisson", 3, 12), ("elasticity", 3, 5), ("elasticity", 3, 8), ("elasticity_voigt", 2, 40)]
+
+
+def test_register_resident_front_kernel_equals_the_launch_sequence_it_replaces(tmp_path):
+    """csrc/mf_front.hip (round 4): groups of small fronts are built, eliminated and reduced to their update matrix in ONE launch with
+    the front in registers.  Same tree, same arithmetic up to the order of the sums: compared with the launch sequence it replaces
+    (HOMMX_MF_FRONT=0: k_mf_build / k_mf_pad / recursive inverse / GEMMs) on every variant of the kernel -- one wave (T <= 4, T <= 6), four
+    waves (T <= 8, T <= 12), eight waves (T <= 19); one, two and three unknowns per node; leaf fronts and fronts with children; with
+    smaller leaves (HOMMX_MF_LEAF=12) the 3D-elasticity tree of the C4 / C5 size class runs its two lowest levels on it -- and against the
+    oracle.  A bad cell is flagged by the front kernel's pivot check and does not leak."""
+    code = f"""
+        import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import numpy as np
+        from hommx_amd import MicroCellPlan
+        from test_gpu_small_wave import _inputs
+        from test_gpu_multifrontal import _FRONT_CASES
+        out = {{}}
+        for kind, dim, n in _FRONT_CASES:
+            p = MicroCellPlan(dim, n, kind)
+            assert p.kernel == "multifrontal", (kind, dim, n, p.kernel)
+            coef, M = _inputs(p, kind, dim, 6, 11)
+            coef[4] = -np.abs(coef[4])          # not SPD: info must say so, the other cells must not notice
+            A, info = p.solve(coef, M, return_info=True)
+            assert info[4] > 0 and not np.delete(info, 4).any(), (kind, dim, n, info)
+            out[f"{{kind}}_{{dim}}_{{n}}"] = np.delete(A, 4, axis=0)
+        np.savez(sys.argv[1], **out)
+        print("ok")
+    """
+    res = {}
+    for tag, env in (("front", {}), ("sequence", {"HOMMX_MF_FRONT": "0"}), ("front_leaf12", {"HOMMX_MF_LEAF": "12"})):
+        f = str(tmp_path / f"{tag}.npz")
+        _child(code.replace("sys.argv[1]", repr(f)), env)
+        res[tag] = dict(np.load(f))
+    for key in res["front"]:
+        a, b, c = res["front"][key], res["sequence"][key], res["front_leaf12"][key]
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (key, np.abs(a - b).max() / np.abs(b).max())
+        assert np.abs(c - b).max() <= 1e-11 * np.abs(b).max(), (key, np.abs(c - b).max() / np.abs(b).max())
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hommx_amd import MicroCellPlan
+    from oracle import hommx_oracle as O
+    from test_gpu_small_wave import _inputs, _oracle_args
+
+    for kind, dim, n in (("poisson", 2, 64), ("elasticity", 2, 28), ("elasticity", 3, 5)):
+        p = MicroCellPlan(dim, n, kind)
+        coef, M = _inputs(p, kind, dim, 6, 11)
+        okind, ocoef = _oracle_args(O, kind, dim, coef)
+        ref = O.effective_tensor_batch(okind, dim, n, ocoef[:2], M[:2])
+        got = res["front"][f"{kind}_{dim}_{n}"][:2]
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max(), (kind, dim, n)
