@@ -40,8 +40,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 FP64_PEAK_DATASHEET = 78.6e12  # FLOP/s, AMD MI355X datasheet: FP64 vector == FP64 matrix (absent from the local guide)
-PMC_SUMMARY = os.path.join("profiles", "r03_c2_pmc_summary.json")
-MF_PMC_SUMMARY = os.path.join("profiles", "r03_mf_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_c2_pmc_summary.json")
+MF_PMC_SUMMARY = os.path.join("profiles", "r04_mf_pmc_summary.json")
 
 
 def flop_model(n: int, b: int | None = None) -> float:

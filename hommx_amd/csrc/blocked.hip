@@ -1204,9 +1204,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_gemm_tile(int M, int N, int K, d
   fetch(0);
   stash();
   __syncthreads();
+  // a diagonal tile of a GATHERING lower-triangle update (its epilogue stores nothing above the diagonal; the plain epilogue stores diagonal
+  // tiles whole, and the recursive inverse reads them whole): the wave(s) whose sub-tile lies strictly above the diagonal -- wave 1 of the
+  // 2 x 2 grid of a 64-tile -- keep staging operands and keeping the barriers, but issue no LDS reads and no MFMAs
+  const bool idle = GATHER && lowerOnly && tx == ty && wj0 >= wi0 + WTM;
   for (int k0 = 0; k0 < K; k0 += 16) {
     const bool more = k0 + 16 < K;
     if (more) fetch(k0 + 16);
+    if (!idle)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       double af[NFA], bf[NFB];

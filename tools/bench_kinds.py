@@ -9,8 +9,9 @@ only_small = "--small" in sys.argv
 dev = torch.device("cuda:0")
 cases = [(2, 10, "elasticity", 0, 8192), (3, 6, "poisson", 0, 8192), (2, 16, "poisson_matrix", 0, 8192), (3, 8, "poisson", 0, 4096),
          (2, 32, "poisson", 1, 4096), (2, 32, "poisson_matrix", 0, 4096), (2, 32, "elasticity", 0, 4096), (2, 16, "elasticity", 0, 4096),
-         (2, 64, "poisson", 0, 2048), (3, 8, "poisson", 0, 2048), (3, 16, "poisson", 0, 1024), (3, 8, "elasticity", 0, 1024),
-         (3, 12, "elasticity", 0, 1024), (3, 16, "elasticity", 0, 1024)]
+         (2, 64, "poisson", 0, 2048), (3, 8, "poisson", 0, 2048), (2, 64, "elasticity", 0, 2048), (2, 96, "poisson", 0, 2048),
+         (2, 128, "poisson", 0, 2048), (3, 9, "poisson", 0, 1024), (3, 12, "poisson", 0, 1024), (3, 16, "poisson", 0, 1024),
+         (3, 8, "elasticity", 0, 1024), (3, 12, "elasticity", 0, 1024), (3, 16, "elasticity", 0, 1024)]
 if only_small:
     cases = cases[:4]
 for a in sys.argv[1:]:  # --case=dim,n,kind,cells

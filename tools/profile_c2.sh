@@ -9,7 +9,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT profiles
-CMD="python3 bench.py --no-cpu-baseline --no-host-boundary --steps 20 --warmup 3"
+CMD="python3 bench.py --no-c5 --no-cpu-baseline --no-host-boundary --steps 20 --warmup 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o run -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o run -- $CMD > $OUT/write.log 2>&1
@@ -29,7 +29,7 @@ per = lambda c: e[c]["per_dispatch"]
 fetch, write = per("FETCH_SIZE") * 1024, per("WRITE_SIZE") * 1024
 avg_ns = [float(r[3]) for r in rows[1:] if "k_poisson2d_fused<32>" in r[0]][0]
 s = {
-    "command": "tools/profile_c2.sh: rocprofv3 --pmc <counters> -- python3 bench.py --no-cpu-baseline --no-host-boundary --steps 20 --warmup 3 (separate passes: FETCH_SIZE; WRITE_SIZE; two SQ sets), summarised by tools/pmc_summary.py",
+    "command": "tools/profile_c2.sh: rocprofv3 --pmc <counters> -- python3 bench.py --no-c5 --no-cpu-baseline --no-host-boundary --steps 20 --warmup 3 (separate passes: FETCH_SIZE; WRITE_SIZE; two SQ sets), summarised by tools/pmc_summary.py",
     "kernel": "k_poisson2d_fused<32>",
     "cells_per_launch": 8192,
     "kernel_avg_ns_kernel_trace": avg_ns,
