@@ -11,6 +11,13 @@
 
 namespace hommx {
 
+#ifdef MFF_PROF  // dev builds: clocks per phase (wave 0 of every workgroup), read by hommx_mff_prof_read
+__device__ unsigned long long mff_prof[16];
+#define MFF_T(i) do { if (tid == 0) { const unsigned long long now__ = clock64(); atomicAdd(&mff_prof[i], now__ - t_prev__); t_prev__ = now__; } } while (0)
+#else
+#define MFF_T(i)
+#endif
+
 // compile-time loop: the tiles of a wave are separate registers, never an indexed array (a loop the compiler declines to unroll would send
 // the whole front to scratch memory)
 template <int I, int N, class F>
@@ -83,6 +90,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
         for (int q = tid; q < ncodes; q += 64 * NW) sc[q] = gcode[q];
       }
     }
+#ifdef MFF_PROF
+    unsigned long long t_prev__ = clock64();
+#endif
     // ---- tables of this front into LDS
     for (int u = tid; u < 16 * T; u += 64 * NW) {
       int gn = -1, node = 0, comp = 0;
@@ -114,55 +124,102 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
     const double* Bc = Brhs + cell * (long long)t * BS * nn;
     mff_sync<NW>();
 
+    MFF_T(0);
     // ---- 1. build: acc[tt] = upper tile e = w + tt NW; lane (k, j), register r: entry (row 16 a + 4 r + k, column 16 b + j).
-    // Branch-free: every entry issues its (at most three) loads unconditionally -- an absent contribution reads a valid dummy address
-    // and is dropped by a select -- so that the (up to twelve) loads of a tile are in flight together; with a branch per contribution
-    // a front's build is a chain of dozens of dependent memory round trips.
+    // Per tile and contribution the loads are issued unconditionally -- an absent contribution reads a valid dummy address and is dropped by
+    // a select -- so that the (up to twelve) loads of a tile are in flight together.
+    // The children's update matrices are stored by rows of the LATER unknown (lower triangle): in the orientation of an upper tile the 16
+    // lanes of a lane row run along the later unknown, i.e. down a COLUMN of the child -- 64 cache lines per load instruction.  The child
+    // part is therefore gathered in the transposed orientation (lanes along the EARLIER unknown: 128-byte segments of the child's rows, four
+    // lines per instruction) and turned round through a 16 x 17 LDS scratch.
     v4d acc[TPW];
+    const int L0 = ch0.L, L1 = ch1.L, KS = BS * BS * nn;
+    double* const tscb = NW == 1 ? Qp : Yp + w * 272;  // both buffers are free until the first panel
+    // (a, b) of this wave's tile tt: a compile-time constant on the one-wave variants (tiles numbered column by column), a table look-up
+    // otherwise (tiles numbered row by row: the tiles with eliminated rows come first)
+    auto tile_ab = [&](auto tc, int& a, int& b) {
+      constexpr int tt = decltype(tc)::value;
+      if constexpr (NW == 1) {
+        a = mff_row(tt);
+        b = mff_col(tt);
+      } else {
+        const int e0 = w + tt * NW;
+        const int ab = g.tilemap[e0 < ntiles ? e0 : 0];
+        a = ab >> 8;
+        b = ab & 255;
+      }
+    };
+    constexpr int NG = (TPW + FENCE - 1) / FENCE;  // groups of FENCE tiles whose loads are in flight together
+    // pass A: the children's update matrices.  Straight-line code per group (a tile this wave does not own contributes masked dummy loads),
+    // fenced between groups so that the scheduler cannot hoist every tile's loads to the top (more registers than the front itself)
+    if (g.has_children) {
+      mff_for<0, NG>([&](auto gc) {
+        constexpr int g0 = decltype(gc)::value * FENCE;
+        constexpr int GN = g0 + FENCE <= TPW ? FENCE : TPW - g0;
+        if (w + g0 * NW >= ntiles) {  // (wave-uniform) nothing left for this wave
+          mff_for<0, GN>([&](auto ic) { acc[g0 + decltype(ic)::value] = v4d{0.0, 0.0, 0.0, 0.0}; });
+          return;
+        }
+        int o0[GN][4], o1[GN][4];
+        mff_for<0, GN>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, tt = g0 + i;
+          const bool own = w + tt * NW < ntiles;
+          int a, b;
+          tile_ab(std::integral_constant<int, tt>(), a, b);
+          // transposed orientation: lane (k, j), register r: (row 16 b + 4 r + k = the later unknown, column 16 a + j = the earlier one)
+          const int ul = 16 * a + j;
+          const int p0l = own ? s_upos[ul] : -1, p1l = own ? s_upos[NU + ul] : -1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int uh = 16 * b + 4 * r + k;
+            const int p0h = s_upos[uh], p1h = s_upos[NU + uh];
+            const int h0 = p0h > p0l ? p0h : p0l, l0 = p0h > p0l ? p0l : p0h, h1 = p1h > p1l ? p1h : p1l, l1 = p1h > p1l ? p1l : p1h;
+            o0[i][r] = l0 >= 0 ? h0 * L0 + l0 : -1;   // (upos is -1 for padding and for an absent child)
+            o1[i][r] = l1 >= 0 ? h1 * L1 + l1 : -1;
+          }
+        });
+        double v0[GN][4], v1[GN][4];
+#pragma unroll
+        for (int i = 0; i < GN; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v0[i][r] = U0[o0[i][r] >= 0 ? o0[i][r] : 0];
+            v1[i][r] = U1[o1[i][r] >= 0 ? o1[i][r] : 0];
+          }
+        mff_for<0, GN>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          v4d vt;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vt[r] = (o0[i][r] >= 0 ? v0[i][r] : 0.0) + (o1[i][r] >= 0 ? v1[i][r] : 0.0);
+          acc[g0 + i] = accl::transpose_tile(vt, tscb, j, k);
+        });
+        asm volatile("" ::: "memory");
+      });
+    } else {
+      mff_for<0, TPW>([&](auto tc) { acc[decltype(tc)::value] = v4d{0.0, 0.0, 0.0, 0.0}; });
+    }
+    // pass B: tiles whose row block is eliminated here (a < P): stencil entries / canonical loads / identity padding.  Off the diagonal
+    // tiles the row unknown is the earlier one (lo); inside a diagonal tile either order occurs.
+    const int e_u = P * T - P * (P - 1) / 2;  // (row-by-row numbering) tiles with a < P are the first e_u
     mff_for<0, TPW>([&](auto tc) {
       constexpr int tt = decltype(tc)::value;
-      acc[tt] = v4d{0.0, 0.0, 0.0, 0.0};
       const int e = w + tt * NW;
       if (e >= ntiles) return;
+      if constexpr (NW > 1) {
+        if (e >= e_u) return;
+      }
       int a, b;
-      if constexpr (NW == 1) { a = mff_row(tt); b = mff_col(tt); }
-      else { const int ab = g.tilemap[e]; a = ab >> 8; b = ab & 255; }
-      if (!g.has_children && a >= P) return;  // leaf fronts: the boundary block starts from zero
-      const int uc = 16 * b + j;
-      const int p0c = s_upos[uc], p1c = s_upos[NU + uc];
-      const int L0 = ch0.L, L1 = ch1.L;
-      if (a >= P) {
-        // both unknowns on the boundary: nothing but the children's update matrices (upos is -1 for padding and for an absent child)
-        int o0[4], o1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ur = 16 * a + 4 * r + k;
-          const int p0r = s_upos[ur], p1r = s_upos[NU + ur];
-          const int h0 = p0r > p0c ? p0r : p0c, l0 = p0r > p0c ? p0c : p0r, h1 = p1r > p1c ? p1r : p1c, l1 = p1r > p1c ? p1c : p1r;
-          o0[r] = l0 >= 0 ? h0 * L0 + l0 : -1;
-          o1[r] = l1 >= 0 ? h1 * L1 + l1 : -1;
-        }
-        double v0[4], v1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v0[r] = U0[o0[r] >= 0 ? o0[r] : 0];
-          v1[r] = U1[o1[r] >= 0 ? o1[r] : 0];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[tt][r] = (o0[r] >= 0 ? v0[r] : 0.0) + (o1[r] >= 0 ? v1[r] : 0.0);
-      } else {
-        // the row block is eliminated here: stencil entries / canonical loads (+ children).  Off the diagonal tiles the row unknown is the
-        // earlier one (lo); inside a diagonal tile either order occurs
+      tile_ab(tc, a, b);
+      if (a < P) {
+        const int uc = 16 * b + j;
         const int gc = s_gnode[uc], rkc = s_rk[uc], ckc = s_ck[uc], n1c = s_n1[uc], nlc = s_nl[uc];
-        const int KS = BS * BS * nn;
         double ident[4];
         const double* pk[4];
         bool okk[4];
-        int o0[4], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ur = 16 * a + 4 * r + k;
-          const int gr = s_gnode[ur], p0r = s_upos[ur], p1r = s_upos[NU + ur];
+          const int gr = s_gnode[ur];
           const bool sw = a == b && ur > uc;
           const int ulo = sw ? uc : ur, uhi = sw ? ur : uc;
           const int glo = sw ? gc : gr, ghi = sw ? gr : gc;
@@ -179,32 +236,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
           const bool okB = elim && !real_hi && m < t;
           pk[r] = okB ? Bc + (m * BS * nn + cklo + glo) : Kc + (okK ? cd * KS + rkhi + cklo : 0);
           okk[r] = okK || okB;
-          const int h0 = p0r > p0c ? p0r : p0c, l0 = p0r > p0c ? p0c : p0r, h1 = p1r > p1c ? p1r : p1c, l1 = p1r > p1c ? p1c : p1r;
-          o0[r] = (elim && l0 >= 0) ? h0 * L0 + l0 : -1;
-          o1[r] = (elim && l1 >= 0) ? h1 * L1 + l1 : -1;
         }
-        double vk[4], v0[4], v1[4];
+        double vk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) vk[r] = *pk[r];
-        if (g.has_children) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v0[r] = U0[o0[r] >= 0 ? o0[r] : 0];
-            v1[r] = U1[o1[r] >= 0 ? o1[r] : 0];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double v = ident[r] + (okk[r] ? vk[r] : 0.0);
-          if (g.has_children) v += (o0[r] >= 0 ? v0[r] : 0.0) + (o1[r] >= 0 ? v1[r] : 0.0);
-          acc[tt][r] = v;
-        }
+        for (int r = 0; r < 4; ++r) acc[tt][r] += ident[r] + (okk[r] ? vk[r] : 0.0);
       }
-      // the loads of FENCE tiles at a time: without a fence the scheduler hoists the loads of ALL tiles to the top, which costs more
-      // registers (pointers, flags) than the front itself and leaves one wave per SIMD
-      if constexpr ((tt + 1) % FENCE == 0) __builtin_amdgcn_sched_barrier(0);
     });
 
+    MFF_T(1);
     // ---- 2. elimination in panels of 16
     int bad = 0;
 #if defined(MFF_PHASE) && MFF_PHASE < 2
@@ -227,11 +268,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
         }
       });
       mff_sync<NW>();
+      MFF_T(2);
       // every wave inverts the diagonal tile itself (no broadcast of N, no second barrier): T = -D, all pivots negative
       double nm[1][1][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) nm[0][0][r] = -Qp[p * 256 + (4 * r + k) * 16 + j];
       accl::Sweep<16>::run(nm, ubuf + w * 64, j, k, bad);   // nm = T^-1 = -N
+      MFF_T(3);
       if constexpr (NW == 1) {
         // one wave: (a, b) of every register set is a compile-time constant and Y'_a stays in registers (in the accumulator layout register q
         // of a tile IS its k-slab q as the A operand of the transpose): no second LDS buffer, no barrier between the products
@@ -267,12 +310,14 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
           for (int r = 0; r < 4; ++r) Yp[a * 256 + (4 * r + k) * 16 + j] = c[r];
         }
         mff_sync<NW>();
+        MFF_T(4);
         // trailing tiles (a, b), p < a <= b:  acc += Y'_a^T E_b^T
         mff_for<0, TPW>([&](auto tc) {
           constexpr int tt = decltype(tc)::value;
           const int e = w + tt * NW;
           if (e < ntiles) {
-            const int ab = g.tilemap[e], a = ab >> 8, b = ab & 255;
+            int a, b;
+            tile_ab(tc, a, b);
             if (a > p) {
               v4d c = acc[tt];
 #pragma unroll
@@ -282,7 +327,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
           }
         });
       }
+      MFF_T(5);
       mff_sync<NW>();  // the next panel overwrites Qp / Yp
+      MFF_T(6);
     }
 
 #if !defined(MFF_PHASE) || MFF_PHASE >= 3 || MFF_PHASE == 1
@@ -309,6 +356,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
       });
     }
 #endif
+    MFF_T(7);
     if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
   }
 }
@@ -348,5 +396,15 @@ void launch_mf_front(const MfFrontDev& g, int bs, const double* Kst, const doubl
 #undef HOMMX_MFF
   }
 }
+
+#ifdef MFF_PROF
+extern "C" void hommx_mff_prof_read(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mff_prof), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mff_prof), z, sizeof(z));
+  }
+}
+#endif
 
 }  // namespace hommx

@@ -218,14 +218,26 @@ std::string mf_describe(const BlockedWorkspace* ws, const MfPlan* p) {
   for (const MfGroup& mg : p->groups) (gemm_tile_size(ws, mg.rp, mg.rp, mg.sp, true) == 128 ? t128 : t64) = true;
   const MfGroup& top = p->groups.back();
   const MfGroup& leaf = p->groups.front();
-  char buf[640];
+  int nfront = 0, ffront = 0;
+  for (const MfGroup& mg : p->groups)
+    if (mg.front) {
+      ++nfront;
+      ffront += mg.nf;
+    }
+  char buf[900];
   snprintf(buf, sizeof(buf),
            "multifrontal: nested dissection, %d fronts in %d groups (leaves s = %d, r = %d x %d; root s = %d), stages of %d unknowns, up to %d stream(s) per "
            "chunk; batched launches per group: k_mf_build, recursive block inverse (k_leaf_inverse / k_leaf_inverse_blk<64> + k_gemm_tile), X = N E^T and "
            "column updates on k_gemm_tile<%s>, gathering Schur update k_gemm_tile<%s%s, GATHER> (the dominant kernel)",
            p->nfronts, (int)p->groups.size(), leaf.ns * ws->G.bs, leaf.rb, leaf.nf, top.ns * ws->G.bs, p->stage, std::max(1, std::min(4, p->streams)),
            ws->gemm128_min < (1 << 29) ? "64x64 / 128x128" : "64x64, 4 waves", t64 ? "64x64, 4 waves" : "", t128 ? (t64 ? " / 128x128, 8 waves" : "128x128, 8 waves") : "");
-  return buf;
+  std::string out = buf;
+  if (nfront) {
+    snprintf(buf, sizeof(buf), "; %d of the groups (%d of the fronts, at most %d x %d unknowns) in ONE launch each on the register-resident front kernel k_mf_front",
+             nfront, ffront, 16 * p->front_max_t, 16 * p->front_max_t);
+    out += buf;
+  }
+  return out;
 }
 
 void mf_plan_destroy(MfPlan* p) {
@@ -506,8 +518,8 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     }
     std::vector<uint16_t> tilemap;
     if (mg.front)
-      for (int b = 0; b < mg.T; ++b)   // column by column: e = b (b + 1) / 2 + a, independent of T (mf_front.hip)
-        for (int a = 0; a <= b; ++a) tilemap.push_back((uint16_t)(a << 8 | b));
+      for (int a = 0; a < mg.T; ++a)   // row by row: the tiles with eliminated rows (a < P) come first (mf_front.hip; the one-wave variants,
+        for (int b = a; b < mg.T; ++b) tilemap.push_back((uint16_t)(a << 8 | b));  // T <= 6, number their tiles column by column without a table)
     if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_dpos, dpos) ||
         upload(&mg.d_child, child) || upload(&mg.d_upos, upos) || upload(&mg.d_tilemap, tilemap)) {
       mf_plan_destroy(P);
