@@ -178,7 +178,9 @@ def test_c5_full_size_chunked_properties():
     for tag, gb in (("small", "1.5"), ("default", None)):
         env = dict(os.environ)
         if gb:
-            env["HOMMX_BLOCKED_MEM_GB"] = gb  # 36 MB per cell => about 40 cells per chunk: 3 chunks for 100 cells
+            # the default plan of this size runs the nested-dissection route: 206 MB of fronts, inverse scratch and stencil per cell
+            # => 7 cells per chunk at 1.5 GB: 15 chunks for 100 cells, every chunk in two pieces on two streams
+            env["HOMMX_BLOCKED_MEM_GB"] = gb
         f = os.path.join("/tmp", f"hommx_c5_chunk_{tag}_{os.getpid()}.npy")
         r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
