@@ -29,6 +29,7 @@ struct MfFrontDev {
   int ns, nloc, sp, rb, L, nf;   // eliminated nodes, nodes of the front, ARENA layout of the group: padded s (multiple of 32), boundary unknowns, ld
   int s16, T, P, ntiles;         // 16-granular: padded s, tiles per dimension, panels (= s16 / 16), upper tiles T (T + 1) / 2
   int has_children;
+  int R0;                        // tile rows [0, R0) of the front live in LDS (k_mf_front's LROWS variants), the rest in registers; tilemap / ntiles: rows >= R0
   long long offF;                // per-cell arena offset of the group's fronts
   const int32_t* nodes;          // [nf][nloc]       global (periodic) node of a local node
   const int8_t* code;            // [nf][nloc][ns]   stencil code of (row node, eliminated column node), -1: none
@@ -37,8 +38,9 @@ struct MfFrontDev {
   const uint16_t* tilemap;       // [ntiles]         a << 8 | b of upper tile e (a <= b), row-major
 };
 
-// most 16-tiles per dimension a front may have to take the kernel (register budget: 8 waves x 24 tiles)
-constexpr int MFF_MAX_T = 19;
+// most 16-tiles per dimension a front may have to take the kernel (register budget: 8 waves x 24 tiles = 192 of the upper tiles)
+constexpr int MFF_REG_TILES = 192;
+constexpr int MFF_MAX_T = 21;   // 19 in registers alone; 20 / 21 with one / two tile rows in LDS
 
 // one launch over `nbatch` = cells x fronts of the group (mf_front.hip); stepcode: value written to info[cell] by a failing pivot check
 void launch_mf_front(const MfFrontDev& g, int bs, const double* Kst, const double* Brhs, double* arena, long long nc, long long nbatch, int nn,

@@ -68,6 +68,7 @@ struct MfGroup {
   // register-resident route of the group (mf_front.h: k_mf_front), when the whole front fits the registers of one workgroup
   bool front = false;
   int s16 = 0, T = 0, P = 0, ntiles = 0;   // 16-granular padded s, tiles per dimension, panels, upper tiles
+  int R0 = 0, nreg = 0;             // tile rows [0, R0) live in LDS (fronts of more than MFF_REG_TILES upper tiles), nreg register tiles (rows >= R0)
   int32_t* d_upos = nullptr;        // [nf][2][16 T]  unknown of the front -> unknown of the child's update matrix, -1: none
   uint16_t* d_tilemap = nullptr;    // [ntiles]       a << 8 | b
   bool has_children = false;
@@ -392,9 +393,15 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     mg.T = (mg.s16 + round_up(mg.rb + MF_BORDER, 16)) / 16;
     mg.P = mg.s16 / 16;
     mg.ntiles = mg.T * (mg.T + 1) / 2;
+    mg.R0 = 0;
+    mg.nreg = mg.ntiles;
+    while (mg.nreg > MFF_REG_TILES) {  // the first tile rows move to LDS until the rest fits the registers of eight waves
+      mg.nreg -= mg.T - mg.R0;
+      ++mg.R0;
+    }
     mg.has_children = !s0.children.empty();
     // the root front pins the gauge node (k_mf_pad does that on the launch sequence): it stays there
-    mg.front = mg.T <= P->front_max_t && members[g][0] != nsn - 1 && s0.height < sn[nsn - 1].height;
+    mg.front = mg.T <= P->front_max_t && mg.R0 <= 2 && mg.R0 <= mg.P && members[g][0] != nsn - 1 && s0.height < sn[nsn - 1].height;
     expiry[t] = t;
   }
   for (int k = 0; k < nsn; ++k)
@@ -518,7 +525,7 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     }
     std::vector<uint16_t> tilemap;
     if (mg.front)
-      for (int a = 0; a < mg.T; ++a)   // row by row: the tiles with eliminated rows (a < P) come first (mf_front.hip; the one-wave variants,
+      for (int a = mg.R0; a < mg.T; ++a)   // row by row: the tiles with eliminated rows (a < P) come first (mf_front.hip; the one-wave variants,
         for (int b = a; b < mg.T; ++b) tilemap.push_back((uint16_t)(a << 8 | b));  // T <= 6, number their tiles column by column without a table)
     if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_dpos, dpos) ||
         upload(&mg.d_child, child) || upload(&mg.d_upos, upos) || upload(&mg.d_tilemap, tilemap)) {
@@ -821,7 +828,7 @@ void mf_group_step(BlockedWorkspace* ws, MfPlan* P, const MfHalf& h, const MfGro
   const double* Brhs = P->Brhs + h.base * G.t * bs * G.nn;
   const long long nb = nc * mg.nf;  // matrices in this batch
   if (mg.front) {  // the whole group in ONE launch: fronts live in registers (mf_front.h)
-    MfFrontDev fd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.s16, mg.T, mg.P, mg.ntiles, mg.has_children ? 1 : 0, mg.offF,
+    MfFrontDev fd{mg.ns, mg.ns + mg.nr, mg.sp, mg.rb, mg.L, mg.nf, mg.s16, mg.T, mg.P, mg.nreg, mg.has_children ? 1 : 0, mg.R0, mg.offF,
                   mg.d_nodes, mg.d_code, mg.d_upos, mg.d_child, mg.d_tilemap};
     launch_mf_front(fd, bs, Kst, Brhs, arena, nc, nb, G.nn, G.ncode, G.t, d_info ? d_info + h.c0 : nullptr, gi, st);
     return;
