@@ -3,8 +3,9 @@
     python tools/mf_groups.py PROF_DIR PIECES [--json out.json]
 
 PROF_DIR holds the passes of tools/profile_mf.sh (stats/ = kernel trace, fetch/, write/, sq/ = counter passes).  The route launches group
-after group (multifrontal.hip: mf_solve), and inside a group piece after piece, every piece starting with k_mf_build: the dispatches
-between the (PIECES * g)-th and the (PIECES * (g + 1))-th k_mf_build of a solve belong to group g (leaves first).  Counter passes
+after group (multifrontal.hip: mf_solve), and inside a group piece after piece, every piece starting with k_mf_build -- or consisting of ONE k_mf_front launch (groups on the
+register-resident front kernel): the dispatches between the (PIECES * g)-th and the (PIECES * (g + 1))-th such launch of a solve belong to group g
+(leaves first).  Counter passes
 serialise the kernels, so the dispatch order is the launch order; the kernel trace of a run on ONE stream (HOMMX_MF_STREAMS=1) gives
 per-group times that add up to the wall clock.  HBM bytes: 2 x FETCH_SIZE + WRITE_SIZE in units of 1 KiB (the x 2 as
 MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; uncalibrated for 8-byte gathers -- ratios between levels hold).
@@ -42,7 +43,7 @@ def by_group(disp, pieces):
             if cur is not None and builds:
                 solves.append(cur)
                 cur, builds = None, 0
-        if k == "k_mf_build":
+        if k in ("k_mf_build", "k_mf_front"):  # every group of a piece starts with its build kernel or IS one front-kernel launch
             if cur is None:
                 cur = []
             if builds % pieces == 0:
