@@ -1,7 +1,7 @@
 // mf_front.h -- k_mf_front: ONE launch per group of fronts of the nested-dissection route (multifrontal.hip) for fronts small enough to
 // live in the REGISTERS of one workgroup: a front of L = s + r unknowns (16-granular) is held as its UPPER 16 x 16 tiles in the layout of
-// the f64 MFMA accumulator, spread round-robin over the NW waves of the workgroup (T (T + 1) / 2 tiles of 4 doubles per lane:
-// T = 21 -- the 3D-elasticity leaf front (s, r) = (81, 222 + 8) -- is 29 tiles = 232 VGPRs per lane on 8 waves).  The kernel
+// the f64 MFMA accumulator, spread round-robin over the NW waves of the workgroup (T (T + 1) / 2 tiles of 4 doubles per lane; eight waves x 24
+// tiles = 192 tiles, T <= 19; the 3D-elasticity leaf front (s, r) = (81, 222 + 8), T = 21, keeps its first two tile rows in LDS).  The kernel
 //
 //   1. BUILDS the front in registers: stencil entries (K1 output) + the children's update matrices through the child -> parent maps
 //      (the extend-add), + the canonical loads in the 8 border rows -- nothing of F11 / F21 / F12 ever touches HBM;

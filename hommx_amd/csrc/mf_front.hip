@@ -43,12 +43,12 @@ __device__ __forceinline__ void mff_sync() {
   else __syncthreads();
 }
 
-// BS unknowns per node; NW waves; TMAX: most tiles per dimension; TPW: most tiles per wave (>= ceil(TMAX (TMAX + 1) / 2 / NW)); MINB: waves
-// per SIMD the register allocation must leave room for; FENCE: tiles whose build loads are in flight together; LROWS: most tile rows
-// that live in LDS instead of registers (fronts two tiles per dimension over the register budget -- the 3D-elasticity leaf (81, 222 + 8),
-// T = 21: 231 tiles, 190 of them in registers, the two first tile rows (41 tiles) in LDS: rows 0 and 1 are the first two panels, each is
-// consumed as a panel where it stands and row 1 is updated once in place) (small fronts are bound by the latency of their dependent loads and pivot chains: what
-// hides it is the number of fronts in flight)
+// BS unknowns per node; NW waves; TMAX: most tiles per dimension; TPW: most (register) tiles per wave; MINB: waves per SIMD the register
+// allocation must leave room for (small fronts are bound by the latency of their dependent loads and pivot chains: what hides it is the
+// number of fronts in flight); FENCE: tiles whose build loads are in flight together; LROWS: most tile rows that live in LDS instead of
+// registers (fronts one or two tiles per dimension over the register budget -- the 3D-elasticity leaf (81, 222 + 8), T = 21: 231 tiles, 190
+// of them in registers, the two first tile rows (41 tiles) in LDS: rows 0 and 1 are the first two panels, each is consumed as a panel where
+// it stands and row 1 takes the update of panel 0 in place)
 template <int BS, int NW, int TMAX, int TPW, int MINB, int FENCE, int LROWS = 0>
 __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const double* __restrict__ Kst, const double* __restrict__ Brhs,
                                                       double* __restrict__ arena, long long nc, long long batch0, int nn, int ncode, int t,
@@ -347,12 +347,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
     MFF_T(1);
     // ---- 2. elimination in panels of 16
     int bad = 0;
-#if defined(MFF_PHASE) && MFF_PHASE < 2
-    const int Pn = 0;
-#else
-    const int Pn = P;
-#endif
-    for (int p = 0; p < Pn; ++p) {
+    for (int p = 0; p < P; ++p) {
       // tile (p, b) of the panel sits at Qp[qb + 256 b]: an LDS row is consumed where it stands, a register row is copied to slot b
       const int qb = (LROWS > 0 && p < R0 && p > 0) ? (T - 1) * 256 : 0;
       if (!(LROWS > 0 && p < R0)) {
@@ -449,7 +444,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
       MFF_T(6);
     }
 
-#if !defined(MFF_PHASE) || MFF_PHASE >= 3 || MFF_PHASE == 1
     // ---- 3. the update matrix (lower triangle, arena layout of the group: F22 at (sp, sp), ld = L), rows up to the border
     {
       double* U = arena + nc * g.offF + batch * (long long)g.L * g.L + (long long)g.sp * g.L + g.sp;
@@ -472,7 +466,6 @@ __global__ __launch_bounds__(64 * NW, MINB) void k_mf_front(MfFrontDev g, const 
         }
       });
     }
-#endif
     MFF_T(7);
     if (bad && l == 0 && info) atomicCAS(&info[cell], 0, stepcode);
   }
