@@ -45,6 +45,7 @@ EXPORTED_SYMBOLS = (
     "hommx_unpack_field",
     "hommx_calibrate_fp64",
     "hommx_calibrate_fp64_mfma",
+    "hommx_calibrate_fp64_detail",
     "hommx_last_error",
 )
 
@@ -170,6 +171,8 @@ def load():
     lib.hommx_unpack_field.argtypes = [i64, i32, i32, vp, vp, vp]
     lib.hommx_calibrate_fp64.restype = C.c_int
     lib.hommx_calibrate_fp64.argtypes = [C.c_int, dp, dp]
+    lib.hommx_calibrate_fp64_detail.restype = C.c_int
+    lib.hommx_calibrate_fp64_detail.argtypes = [C.c_int, dp, dp, dp]
     lib.hommx_calibrate_fp64_mfma.restype = C.c_int
     lib.hommx_calibrate_fp64_mfma.argtypes = [C.c_int, dp]
     lib.hommx_last_error.restype = C.c_char_p

@@ -506,5 +506,11 @@ int hommx_calibrate_fp64(int device, double* mfma_flops_per_s, double* fma_flops
 }
 
 int hommx_calibrate_fp64_mfma(int device, double* flops_per_s) { return hommx_calibrate_fp64(device, flops_per_s, nullptr); }
+int hommx_calibrate_fp64_detail(int device, double* mfma_flops_per_s, double* fma_flops_per_s, double* mfma_lds_fed_flops_per_s) {
+  if (!mfma_flops_per_s && !fma_flops_per_s && !mfma_lds_fed_flops_per_s) return fail(HOMMX_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hommx::run_fp64_calibration(mfma_flops_per_s, fma_flops_per_s, mfma_lds_fed_flops_per_s));
+  return HOMMX_OK;
+}
 
 }  // extern "C"

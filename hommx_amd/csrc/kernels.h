@@ -47,7 +47,7 @@ hipError_t launch_expand_two_phase(const unsigned char* d_mask, const double* d_
                                    int n_comp, long long ncells, hipStream_t stream);
 
 // calibrate.hip: best sustained v_mfma_f64_16x16x4_f64 and v_fma_f64 rates over 2 and 4 waves per SIMD.
-hipError_t run_fp64_calibration(double* mfma_flops_per_s, double* fma_flops_per_s);
+hipError_t run_fp64_calibration(double* mfma_flops_per_s, double* fma_flops_per_s, double* mfma_lds_fed_flops_per_s = nullptr);
 
 }  // namespace hommx
 

@@ -237,6 +237,9 @@ int hommx_unpack_field(int64_t n_cells, int32_t ndev, int32_t tt, const double* 
  * hommx_calibrate_fp64_mfma is the MFMA figure alone (kept for callers of the first ABI revision). */
 int hommx_calibrate_fp64(int device, double* mfma_flops_per_s, double* fma_flops_per_s);
 int hommx_calibrate_fp64_mfma(int device, double* flops_per_s);
+/* Same plus a third figure: the MFMA fed from LDS the way the GEMM kernels feed it (16 MFMAs per 16 ds_read_b64).  The dependency-free
+ * pure-MFMA loop clocks down under its own load; this loop is the fp64 matrix rate a real kernel can hold.  Any pointer may be NULL. */
+int hommx_calibrate_fp64_detail(int device, double* mfma_flops_per_s, double* fma_flops_per_s, double* mfma_lds_fed_flops_per_s);
 
 const char* hommx_last_error(void);
 
