@@ -311,7 +311,8 @@ def test_random_sizes_kinds_contrasts_against_the_oracle():
     """, {"HOMMX_MF_MIN_B": "65"})
 
 
-_FRONT_CASES = [("poisson", 2, 64), ("poisson", 2, 100), ("elasticity", 2, 28), ("elasticity", 2, 40), ("poisson_matrix", 2, 72),
+_FRONT_CASES = [("poisson", 2, 64), ("poisson", 2, 100), ("poisson", 2, 120), ("elasticity", 2, 28), ("elasticity", 2, 40), ("elasticity", 2, 62),
+                ("poisson_matrix", 2, 72),
                 ("poisson", 3, 9), ("poisson", 3, 12), ("elasticity", 3, 5), ("elasticity", 3, 8), ("elasticity_voigt", 2, 40)]
 
 
@@ -319,7 +320,8 @@ def test_register_resident_front_kernel_equals_the_launch_sequence_it_replaces(t
     """csrc/mf_front.hip (round 4): groups of small fronts are built, eliminated and reduced to their update matrix in ONE launch with
     the front in registers.  Same tree, same arithmetic up to the order of the sums: compared with the launch sequence it replaces
     (HOMMX_MF_FRONT=0: k_mf_build / k_mf_pad / recursive inverse / GEMMs) on every variant of the kernel -- one wave (T <= 4, T <= 6), four
-    waves (T <= 8, T <= 12), eight waves (T <= 19); one, two and three unknowns per node; leaf fronts and fronts with children; with
+    waves (T <= 8, T <= 12), eight waves (T <= 19; T = 20 / 21 with one / two tile rows in LDS: 2D Poisson 120^2 and 2D elasticity 62^2 have a
+    T = 20 level, 3D elasticity 8^3 the T = 21 leaf of C4 / C5); one, two and three unknowns per node; leaf fronts and fronts with children; with
     smaller leaves (HOMMX_MF_LEAF=12) the 3D-elasticity tree of the C4 / C5 size class runs its two lowest levels on it -- and against the
     oracle.  A bad cell is flagged by the front kernel's pivot check and does not leak."""
     code = f"""
