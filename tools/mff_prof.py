@@ -1,4 +1,4 @@
-"""Dev tool: per-phase clocks of the register-resident front kernel (library built with -DMFF_PROF -DMFF_DEV_BS3, HOMMX_LIB points at it):
+"""Dev tool: per-phase clocks of the register-resident front kernel (library whose mf_front_bs3.hip was compiled with -DMFF_PROF [-DMFF_DEV_BS3], HOMMX_LIB points at it):
 phases 0 tables, 1 build, 2 panel -> LDS + barrier, 3 sweep, 4 Y' + barrier, 5 updates, 6 barrier, 7 store (summed over wave 0 of every workgroup)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
