@@ -954,7 +954,7 @@ int blocked_workspace_create(BlockedWorkspace** out, int dim, int n, int kind) {
   // block b > 64, i.e. everything the one-launch kernels do not take: 2D scalar n = 80: +51 %, 2D elasticity n = 36: +92 %, 3D elasticity
   // n = 5: +68 %, n = 16: +76 %, scalar 3D n = 9: +18 % (it lost 10 % there before the build kernel batched its loads and the route ran on
   // two streams)
-  // Round 4: with the register-resident front kernel (mf_front.hip: one launch per tree level, fronts never leave the registers) the tree
+  // Round 4: with the register-resident front kernel (mf_front_kernel.h: one launch per tree level, fronts never leave the registers) the tree
   // also beats the LDS kernel of csrc/small_fused.h on 2D meshes with 48 < b <= 64: 2D Poisson 64^2 175 k -> 256 k solves/s, 2D elasticity
   // 32^2 320 k -> 336 k; it loses on 3D Poisson 8^3 (1.25 M -> 0.79 M: few, larger fronts) and against the one-wave kernel (b <= 48).
   ws->mf_min_b = dim == 2 ? 49 : 65;

@@ -42,7 +42,7 @@ struct MfFrontDev {
 constexpr int MFF_REG_TILES = 192;
 constexpr int MFF_MAX_T = 21;   // 19 in registers alone; 20 / 21 with one / two tile rows in LDS
 
-// one launch over `nbatch` = cells x fronts of the group (mf_front.hip); stepcode: value written to info[cell] by a failing pivot check
+// one launch over `nbatch` = cells x fronts of the group (mf_front_kernel.h); stepcode: value written to info[cell] by a failing pivot check
 void launch_mf_front(const MfFrontDev& g, int bs, const double* Kst, const double* Brhs, double* arena, long long nc, long long nbatch, int nn,
                      int ncode, int t, int32_t* info, int stepcode, hipStream_t st);
 

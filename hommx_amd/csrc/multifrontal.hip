@@ -525,7 +525,7 @@ int mf_plan_create(MfPlan** out, const Geo& G, bool keep) {
     }
     std::vector<uint16_t> tilemap;
     if (mg.front)
-      for (int a = mg.R0; a < mg.T; ++a)   // row by row: the tiles with eliminated rows (a < P) come first (mf_front.hip; the one-wave variants,
+      for (int a = mg.R0; a < mg.T; ++a)   // row by row: the tiles with eliminated rows (a < P) come first (mf_front_kernel.h; the one-wave variants,
         for (int b = a; b < mg.T; ++b) tilemap.push_back((uint16_t)(a << 8 | b));  // T <= 6, number their tiles column by column without a table)
     if (upload(&mg.d_nodes, nodes) || upload(&mg.d_code, code) || upload(&mg.d_cpos, cpos) || upload(&mg.d_dpos, dpos) ||
         upload(&mg.d_child, child) || upload(&mg.d_upos, upos) || upload(&mg.d_tilemap, tilemap)) {

@@ -57,7 +57,7 @@ extern "C" {
  *                          elimination (default: 65 in 3D, 49 in 2D, i.e. every plane block the one-launch kernels do not take or lose
  *                          on; 0: never; a value below 65 from the environment needs HOMMX_NO_SMALL_FUSED as well)
  *   HOMMX_MF_FRONT         most 16 x 16 tiles per dimension of a front that is eliminated by the register-resident front kernel
- *                          (csrc/mf_front.hip: one launch per tree level) instead of the build / inverse / GEMM launch sequence
+ *                          (csrc/mf_front_kernel.h: one launch per tree level) instead of the build / inverse / GEMM launch sequence
  *                          (default and maximum 19; 0: never)
  *   HOMMX_MF_STREAMS       1: the nested-dissection route runs on the caller's stream alone (default 4: every chunk as two to four pieces side
  *                          by side on the caller's stream and plan-owned ones; the caller's stream waits for all, results are bitwise equal)

@@ -317,7 +317,7 @@ _FRONT_CASES = [("poisson", 2, 64), ("poisson", 2, 100), ("poisson", 2, 120), ("
 
 
 def test_register_resident_front_kernel_equals_the_launch_sequence_it_replaces(tmp_path):
-    """csrc/mf_front.hip (round 4): groups of small fronts are built, eliminated and reduced to their update matrix in ONE launch with
+    """csrc/mf_front_kernel.h (round 4): groups of small fronts are built, eliminated and reduced to their update matrix in ONE launch with
     the front in registers.  Same tree, same arithmetic up to the order of the sums: compared with the launch sequence it replaces
     (HOMMX_MF_FRONT=0: k_mf_build / k_mf_pad / recursive inverse / GEMMs) on every variant of the kernel -- one wave (T <= 4, T <= 6), four
     waves (T <= 8, T <= 12), eight waves (T <= 19; T = 20 / 21 with one / two tile rows in LDS: 2D Poisson 120^2 and 2D elasticity 62^2 have a

@@ -31,7 +31,7 @@ CASES = [
     ("elasticity", 3, 4),         # b 48, t 6: NT 3, slab form
     ("poisson_matrix", 2, 47),    # b 47, t 2: NT 3, slab form (b + t = 49)
     ("poisson", 3, 7),            # b 49: LDS kernel (48 < b <= 64, csrc/small_fused.h), 13 of 16 k-slabs
-    ("elasticity", 2, 28),        # b 56 on a 2D mesh: nested dissection since round 4 (register-resident fronts, csrc/mf_front.hip)
+    ("elasticity", 2, 28),        # b 56 on a 2D mesh: nested dissection since round 4 (register-resident fronts, csrc/mf_front_kernel.h)
     ("poisson", 3, 8),            # b 64: LDS kernel, all 16 k-slabs
 ]
 
